@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the IB-LBM hot path on MI355X.
+
+Metric (BASELINE.json): MLUPS (+ cell-vertex updates/s) on a synthetic pipeflow at 10 % hematocrit.
+A "step" is one HemoCell::iterate(): spread -> collide-stream -> [interpolate] -> advance -> [mechanics]
+with the reference's pipeflow cadences (stepParticleEvery 5, stepMaterialEvery 20,
+examples/pipeflow/config.xml:19-20).  Inputs are resident in HBM before the timed region.
+
+N GPUs (weak scaling): the pipe is N x (256x256x256) long; each rank owns one 256-plane x-slab with its
+own cells, x-halos are exchanged every step over RCCL (torch.distributed, backend nccl).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--nx", type=int, default=256, help="slab thickness per GPU")
+    ap.add_argument("--ny", type=int, default=256)
+    ap.add_argument("--nz", type=int, default=256)
+    ap.add_argument("--hematocrit", type=float, default=0.10)
+    ap.add_argument("--fluid-only", action="store_true", help="cases/performance_testing style ceiling run")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, budget_s):
+    """the oracle (CPU restatement, "kind": "port") on a bounded sample of the same workload: a
+    64x128x128 pipe at the same hematocrit and cadences, all host cores (OpenMP collide-stream)."""
+    import ctypes as C
+
+    from hemocell_amd.packing import pack_pipe_rbc
+    from hemocell_amd.host import pipe_mask
+    from oracle import oracle as O
+
+    orc = O.load()
+    nx, ny, nz = 64, 128, 128
+    cores = min(os.cpu_count() or 1, 64)
+    P = O.make_params(orc)
+    mask, R = pipe_mask(nx, ny, nz)
+    L = O.OracleLattice(orc, nx, ny, nz, (1, 0, 0), 1.0 / P.tau)
+    L.set_mask(mask); L.init_equilibrium(); L.set_threads(cores)
+    S = orc.orc_sim_create(L.ptr, C.byref(P))
+    T = O.make_rbc(orc, P); T.contents.timescale = 20
+    orc.orc_sim_add_type(S, T)
+    S.contents.particle_velocity_timescale = 5
+    ncell = 0
+    if not args.fluid_only:
+        centres, angles = pack_pipe_rbc(nx, ny, nz, args.hematocrit)
+        for c, a in zip(centres, angles):
+            ar = np.array(a) * (3.14159265358979323846 / 180.0) * -1.0
+            ncell += orc.orc_sim_add_cell(S, 0, O.dptr(np.ascontiguousarray(c)), O.dptr(ar), 0.0)
+    F = body_force(ny, P.nu_lbm)
+    L.set_force_uniform(F)
+    for d in range(3):
+        S.contents.body_force[d] = F[d]
+    orc.orc_sim_mechanics(S, 1)
+    orc.orc_sim_iterate(S)  # warm
+    t0 = time.perf_counter(); steps = 0
+    while time.perf_counter() - t0 < budget_s and steps < 200:
+        orc.orc_sim_iterate(S); steps += 1
+    dt = time.perf_counter() - t0
+    nverts = S.contents.np
+    return {"value": nx * ny * nz * steps / dt / 1e6, "unit": "MLUPS", "cores": cores, "kind": "port",
+            "sample": "oracle (oracle/hemo_oracle.c, OpenMP collide-stream, serial IBM/mechanics), pipe %dx%dx%d, %d RBC "
+                      "(%d vertices), %d steps in %.1f s" % (nx, ny, nz, ncell, nverts, steps, dt),
+            "vertex_updates_per_s": nverts * steps / dt}
+
+
+def body_force(ny, nu_lbm, Re=0.5):
+    """poiseuilleForce of examples/pipeflow/pipeflow.cpp:80: 8 nu (u_max/2) / R^2 with u_max = Re nu / (2R)"""
+    R = (ny - 2) / 2.0
+    u_max = Re * nu_lbm / (2 * R)
+    return (8.0 * nu_lbm * (u_max * 0.5) / (R * R), 0.0, 0.0)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    import torch
+    import torch.distributed as dist
+
+    from hemocell_amd import host
+    from hemocell_amd.packing import pack_pipe_rbc
+    from hemocell_amd.slab import SlabRunner
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    host.init(local_rank)
+
+    P = host.base_parameters()  # examples/pipeflow/config.xml:25-28: dx 5e-7, dt 1e-7, nuP 1.1e-6 -> tau 1.82
+    nxg = args.nx * world
+    runner = SlabRunner(nx_local=args.nx, ny=args.ny, nz=args.nz, rank=rank, world=world, P=P,
+                        periodic=(True, False, False), particle_timescale=5, material_timescale=20,
+                        deletion_check_every=1000000)
+    mask, R = host.pipe_mask(nxg, args.ny, args.nz)
+    runner.define_bounce_back(mask)
+    runner.lattice.latticeEquilibrium(1.0, (0, 0, 0))
+    runner.lattice.setExternalVector(body_force(args.ny, P.nu_lbm))
+    n_cells = 0
+    if not args.fluid_only:
+        rbc = host.CellType.rbc(P)
+        runner.add_cell_type(rbc)
+        centres, angles = pack_pipe_rbc(nxg, args.ny, args.nz, args.hematocrit)
+        n_cells = runner.load_cells(0, centres, angles)
+    runner.prepare()
+    nverts_local = runner.owned_vertices()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        host.capi.check(host.capi.lib().hc_synchronize())
+
+    runner.run(args.warmup)
+    host.capi.lib().hc_profile_reset()
+    host.capi.lib().hc_profile_enable(1)
+    barrier()
+    t0 = time.perf_counter()
+    runner.run(args.steps)
+    barrier()
+    t1 = time.perf_counter()
+    host.capi.lib().hc_profile_enable(0)
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed, float(nverts_local)], dtype=torch.float64, device="cuda")
+        tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0]); nverts = int(tsum[1])
+    else:
+        nverts = nverts_local
+
+    import ctypes as C
+    ms, n = C.c_double(), C.c_long()
+    host.capi.check(host.capi.lib().hc_profile_read(b"collide_stream", C.byref(ms), C.byref(n)))
+    prof = {}
+    for k in ("collide_stream", "ibm_spread", "ibm_interpolate", "advance", "mechanics"):
+        m2, n2 = C.c_double(), C.c_long()
+        host.capi.check(host.capi.lib().hc_profile_read(k.encode(), C.byref(m2), C.byref(n2)))
+        prof[k] = {"ms_total": m2.value, "launches": n2.value}
+
+    if rank == 0:
+        nodes = nxg * args.ny * args.nz
+        mlups = nodes * args.steps / elapsed / 1e6
+        bytes_per_node = runner.lattice.bytes_per_node() if not args.fluid_only else runner.lattice.bytes_per_node()
+        avg_ms = ms.value / max(n.value, 1)
+        launch_nodes = args.nx * args.ny * args.nz
+        achieved = launch_nodes * bytes_per_node / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "MLUPS + cell-vertex updates/s, 256^3 pipeflow 10% Hct",
+            "value": mlups, "unit": "MLUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vertex_updates_per_s": nverts * args.steps / elapsed,
+            "config": {"workload": "examples/pipeflow synthetic: pipe %dx%dx%d (x periodic, analytic cylinder R=%.0f, bounce-back), "
+                                   "%d RBC (rbcHighOrderModel, 642 vertices each, target Hct %.2f), tau=%.2f, "
+                                   "stepParticleEvery=5, stepMaterialEvery=20%s"
+                                   % (nxg, args.ny, args.nz, R, n_cells, args.hematocrit, P.tau, ", fluid only" if args.fluid_only else ""),
+                       "lattice": [nxg, args.ny, args.nz], "cells": n_cells, "vertices": nverts,
+                       "parallelism": "x-slabs x%d, RCCL halo exchange" % world},
+            "roofline": {"bound": "hbm", "kernel": "collide_stream_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "bytes_per_node": bytes_per_node, "avg_launch_ms": avg_ms, "launches": n.value},
+            "kernel_ms": prof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

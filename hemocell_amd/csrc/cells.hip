@@ -1,0 +1,1019 @@
+// Membrane vertices on the GPU: phi2 immersed-boundary spread / interpolate,
+// Euler advance, rbcHighOrderModel and pltSimpleModel forces.
+//
+// Replaces (file:line in the HemoCell tree):
+//   core/immersedBoundaryMethod.h:62-138          interpolationCoefficientsPhi2
+//   core/hemoCellParticleField.cpp:841-863        spreadParticleForce
+//   core/hemoCellParticleField.cpp:819-839        interpolateFluidVelocity
+//   core/hemoCellParticle.h:188-203, core/hemoCellParticleField.cpp:566-588   advance
+//   core/hemoCellParticleField.cpp:633-675        applyConstitutiveModel
+//   mechanics/rbcHighOrderModel.cpp:38-207, mechanics/pltSimpleModel.cpp:44-208
+//
+// Layout (HBM): vertices are a structure of arrays pos/vel/frc[3][n], cell
+// major (a cell's nv vertices are contiguous, cells of one type contiguous), so
+// a wavefront touches 64 consecutive doubles per component and a mechanics
+// workgroup stages one whole cell in LDS with coalesced loads.
+//
+// The membrane models are evaluated in GATHER form: one workgroup per cell,
+// vertex positions in LDS, each vertex sums the contributions of its incident
+// triangles / ring / edges in exactly the order in which the reference's
+// scatter loops would have added them (triangle loop, volume loop, vertex
+// loop, edge loop), so no atomics are needed and the result is reproducible
+// and (with -ffp-contract=off) bit-identical to the scatter form.
+#include "common.h"
+#include "mesh.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+using namespace hc;
+
+struct hc_celltype {
+  CellTables host;
+  int *d_tri = nullptr, *d_edge = nullptr, *d_ebt = nullptr, *d_ebo = nullptr, *d_iedge = nullptr;
+  int *d_vtri = nullptr, *d_vtri_k = nullptr, *d_vedge = nullptr, *d_vedge_s = nullptr, *d_bsrc = nullptr;
+  int *d_vouter = nullptr, *d_vinner = nullptr, *d_vinner_s = nullptr, *d_ring = nullptr, *d_nring = nullptr;
+  double *d_tri_area_eq = nullptr, *d_edge_len_eq = nullptr, *d_edge_angle_eq = nullptr, *d_patch_eq = nullptr,
+         *d_iedge_len_eq = nullptr;
+};
+
+struct hc_cells {
+  hc_lattice *L = nullptr;
+  hc_params P;
+  int ntypes = 0;
+  hc_celltype *types[8];
+  int timescale[8];
+  std::vector<double> hpos[8];   // host staging per type: [ncells*nv][3]
+  std::vector<double> hvel[8], hfrc[8];
+  std::vector<long> hids[8];
+  bool host_dirty = false;       // host staging newer than device
+  long nverts = 0, cap = 0;
+  long ncells[8] = {0};
+  long first[8] = {0};           // first vertex of each type on the device
+  double *pos[3] = {nullptr, nullptr, nullptr}, *vel[3] = {nullptr, nullptr, nullptr}, *frc[3] = {nullptr, nullptr, nullptr};
+  int *d_tag = nullptr;          // per-cell deletion tags (all types, slot order)
+  long tag_cap = 0;
+  int *h_ntag = nullptr;         // pinned host copy of the tag counter
+  int *d_ntag = nullptr;         // device counter of tagged cells
+  int *d_vert_cell = nullptr;    // [cap] cell slot of every vertex
+  long n_deleted = 0;
+};
+
+namespace {
+
+// ----------------------------------------------------------------------------
+// lattice view for the IBM kernels
+struct LatView {
+  const uint8_t *mask;
+  int nx, ny, nz, plane; long npad;
+  int x0;                 // global x of local plane 0
+  int wrap_x, halo_x;     // single periodic slab: wrap; multi slab: one halo plane is addressable
+  int per_y, per_z;
+  int nx_global;
+};
+
+LatView make_view(const hc_lattice *L) {
+  LatView v;
+  v.mask = L->mask; v.nx = L->nx; v.ny = L->ny; v.nz = L->nz; v.plane = (int)L->plane; v.npad = (long)L->npad;
+  v.x0 = L->x0; v.wrap_x = (L->n_slabs == 1 && L->periodic[0]) ? 1 : 0; v.halo_x = L->n_slabs > 1 ? 1 : 0;
+  v.per_y = L->periodic[1]; v.per_z = L->periodic[2]; v.nx_global = L->nx_global;
+  return v;
+}
+
+__device__ __forceinline__ long pmod(long a, long n) { long r = a % n; return r < 0 ? r + n : r; }
+
+// phi2 (core/immersedBoundaryMethod.h:37-41)
+__device__ __forceinline__ double phi2(double x) { x = fabs(x); x = 1.0 - x; return x > 0.0 ? x : 0.0; }
+
+struct Stencil {
+  long node[8];     // padded-lattice element index, -1 when not admitted
+  double w[8];      // normalised weights
+  int lx[8], ly[8], lz[8];  // local (wrapped) coordinates of the node, for the population gather
+};
+
+// interpolationCoefficientsPhi2 (core/immersedBoundaryMethod.h:62-138).  Per axis only the pair
+// {centre-1, centre} (x < centre) or {centre, centre+1} can carry a non-zero tent weight, and visiting
+// the 2x2x2 pairs in ascending offset order is the reference's 27-node loop with its zero-weight skips.
+__device__ __forceinline__ void phi2_stencil(const LatView &v, double px, double py, double pz, Stencil &s) {
+  const double p[3] = {px - (double)v.x0, py, pz};
+  long c[3]; int d0[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) { c[a] = (long)(p[a] + 0.5); d0[a] = (p[a] < (double)c[a]) ? -1 : 0; }
+  double total = 0.0;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int idx = i * 4 + j * 2 + k;
+        const long gx = c[0] + d0[0] + i, gy = c[1] + d0[1] + j, gz = c[2] + d0[2] + k;
+        long lx = gx, ly = gy, lz = gz;
+        bool ok = true;
+        if (v.wrap_x) lx = pmod(gx, v.nx);
+        else if (v.halo_x) ok = ok && (gx >= -1 && gx <= v.nx);
+        else ok = ok && (gx >= 0 && gx < v.nx);
+        if (gy < 0 || gy >= v.ny) { if (v.per_y) ly = pmod(gy, v.ny); else ok = false; }
+        if (gz < 0 || gz >= v.nz) { if (v.per_z) lz = pmod(gz, v.nz); else ok = false; }
+        double weight = 0.0; long node = -1;
+        if (ok) {
+          weight = phi2(p[0] - (double)gx) * phi2(p[1] - (double)gy) * phi2(p[2] - (double)gz);
+          if (weight != 0.0) {
+            node = (lx + HALO) * (long)v.plane + ly * v.nz + lz;
+            if (v.mask[node] != 0) node = -1;
+          }
+        }
+        if (node >= 0) total += weight;
+        s.node[idx] = node; s.w[idx] = weight; s.lx[idx] = (int)lx; s.ly[idx] = (int)ly; s.lz[idx] = (int)lz;
+      }
+  const double coeff = 1.0 / total;
+#pragma unroll
+  for (int idx = 0; idx < 8; idx++) s.w[idx] *= coeff;
+}
+
+// ----------------------------------------------------------------------------
+// spread
+__global__ __launch_bounds__(256) void ibm_spread_kernel(LatView v, long n, const double *px, const double *py, const double *pz,
+                                                         double *fx, double *fy, double *fz, double *F, int limit_on, double f_limit) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double f0 = fx[i], f1 = fy[i], f2 = fz[i];
+  if (limit_on) {  // FORCE_LIMIT cap, core/hemoCellParticleField.cpp:848-852 (mutates sv.force)
+    const double mag = sqrt((f0 * f0 + f1 * f1) + f2 * f2);
+    if (mag > f_limit) {
+      const double sc = f_limit / mag;
+      f0 *= sc; f1 *= sc; f2 *= sc;
+      fx[i] = f0; fy[i] = f1; fz[i] = f2;
+    }
+  }
+  Stencil s;
+  phi2_stencil(v, px[i], py[i], pz[i], s);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (s.node[k] < 0) continue;
+    // external.data[d] += (force_repulsion[d] + force[d]) * weight  (:857-859); repulsion is 0 (disabled in scope)
+    unsafeAtomicAdd(&F[s.node[k]], (0.0 + f0) * s.w[k]);
+    unsafeAtomicAdd(&F[v.npad + s.node[k]], (0.0 + f1) * s.w[k]);
+    unsafeAtomicAdd(&F[2 * v.npad + s.node[k]], (0.0 + f2) * s.w[k]);
+  }
+}
+
+// ----------------------------------------------------------------------------
+// interpolate: v = sum_j w_j * (j/rho + F/2)(node_j) on the post-stream state
+struct PopView {
+  const double *f; const double *F; double bx, by, bz;
+};
+
+__device__ __forceinline__ void node_velocity(const LatView &v, const PopView &pv, int lx, int ly, int lz, long node, double u[3]) {
+  // gather S(node,q) = P(node - c_q, q) with the same wrap rules as the collide kernel
+  long xm = -(long)v.plane, xp = (long)v.plane;
+  if (v.wrap_x) { if (lx == 0) xm = (long)(v.nx - 1) * v.plane; if (lx == v.nx - 1) xp = -(long)(v.nx - 1) * v.plane; }
+  int ym = -v.nz, yp = v.nz, zm = -1, zp = 1; bool ymk = true, ypk = true, zmk = true, zpk = true;
+  if (ly == 0) { if (v.per_y) ym = (v.ny - 1) * v.nz; else ymk = false; }
+  if (ly == v.ny - 1) { if (v.per_y) yp = -(v.ny - 1) * v.nz; else ypk = false; }
+  if (lz == 0) { if (v.per_z) zm = v.nz - 1; else zmk = false; }
+  if (lz == v.nz - 1) { if (v.per_z) zp = -(v.nz - 1); else zpk = false; }
+  double r = 0.0, jx = 0.0, jy = 0.0, jz = 0.0;
+#define M(Q, CX, CY, CZ)                                                              \
+  {                                                                                   \
+    long off = 0; bool ok = true;                                                     \
+    if (CX == 1) off += xm; else if (CX == -1) off += xp;                             \
+    if (CY == 1) { off += ym; ok = ok && ymk; } else if (CY == -1) { off += yp; ok = ok && ypk; } \
+    if (CZ == 1) { off += zm; ok = ok && zmk; } else if (CZ == -1) { off += zp; ok = ok && zpk; } \
+    const double fq = ok ? pv.f[(long)Q * v.npad + node + off] : 0.0;                 \
+    r += fq;                                                                          \
+    if (CX == 1) jx += fq; else if (CX == -1) jx += -fq;                              \
+    if (CY == 1) jy += fq; else if (CY == -1) jy += -fq;                              \
+    if (CZ == 1) jz += fq; else if (CZ == -1) jz += -fq;                              \
+  }
+  M(0, 0, 0, 0) M(1, -1, 0, 0) M(2, 0, -1, 0) M(3, 0, 0, -1) M(4, -1, -1, 0) M(5, -1, 1, 0)
+  M(6, -1, 0, -1) M(7, -1, 0, 1) M(8, 0, -1, -1) M(9, 0, -1, 1) M(10, 1, 0, 0) M(11, 0, 1, 0)
+  M(12, 0, 0, 1) M(13, 1, 1, 0) M(14, 1, -1, 0) M(15, 1, 0, 1) M(16, 1, 0, -1) M(17, 0, 1, 1)
+  M(18, 0, 1, -1)
+#undef M
+  const double invRho = 1.0 / (1.0 + r);
+  u[0] = jx * invRho + (pv.bx + pv.F[node]) / 2.0;
+  u[1] = jy * invRho + (pv.by + pv.F[v.npad + node]) / 2.0;
+  u[2] = jz * invRho + (pv.bz + pv.F[2 * v.npad + node]) / 2.0;
+}
+
+__global__ __launch_bounds__(256) void ibm_interpolate_kernel(LatView v, PopView pv, long n, const double *px, const double *py,
+                                                              const double *pz, double *vx, double *vy, double *vz) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  Stencil s;
+  phi2_stencil(v, px[i], py[i], pz[i], s);
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (s.node[k] < 0) continue;
+    double u[3];
+    node_velocity(v, pv, s.lx[k], s.ly[k], s.lz[k], s.node[k], u);
+    a0 += (u[0] * s.w[k]); a1 += (u[1] * s.w[k]); a2 += (u[2] * s.w[k]);
+  }
+  vx[i] = a0; vy[i] = a1; vz[i] = a2;
+}
+
+// ----------------------------------------------------------------------------
+// advance + boundary tagging
+__global__ __launch_bounds__(256) void advance_kernel(LatView v, long n, double *px, double *py, double *pz, const double *vx,
+                                                      const double *vy, const double *vz, const int *vert_cell, int *tag, int *ntag) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double x = px[i] + vx[i], y = py[i] + vy[i], z = pz[i] + vz[i];
+  px[i] = x; py[i] = y; pz[i] = z;
+  // nearest node is a boundary -> tag (core/hemoCellParticleField.cpp:571-583)
+  long gx = (long)((x - (double)v.x0) + 0.5), gy = (long)(y + 0.5), gz = (long)(z + 0.5);
+  bool inside = true;
+  if (v.wrap_x) gx = pmod(gx, v.nx); else inside = inside && (gx >= (v.halo_x ? -1 : 0) && gx <= (v.halo_x ? v.nx : v.nx - 1));
+  if (gy < 0 || gy >= v.ny) { if (v.per_y) gy = pmod(gy, v.ny); else inside = false; }
+  if (gz < 0 || gz >= v.nz) { if (v.per_z) gz = pmod(gz, v.nz); else inside = false; }
+  if (inside && v.mask[(gx + HALO) * (long)v.plane + gy * v.nz + gz] != 0) {
+    if (atomicExch(&tag[vert_cell[i]], 1) == 0) atomicAdd(ntag, 1);
+  }
+}
+
+// ----------------------------------------------------------------------------
+// membrane mechanics
+struct MechArgs {
+  int model, nv, nt, ne, nie;
+  const int *tri, *edge, *ebt, *ebo, *iedge;
+  const int *vtri, *vtri_k, *vedge, *vedge_s, *bsrc, *vouter, *vinner, *vinner_s, *ring, *nring;
+  const double *tri_area_eq, *edge_len_eq, *edge_angle_eq, *patch_eq, *iedge_len_eq;
+  double volume_eq, area_mean_eq, edge_mean_eq;
+  double k_volume, k_area, k_link, k_bend, eta_m;
+  const double *px, *py, *pz, *vx, *vy, *vz;   // already offset to the type's first vertex
+  double *fx, *fy, *fz;
+  double *comp;        // optional [6][ncells*nv][3]
+  long ncv;            // ncells*nv (stride of comp)
+};
+
+#define MaxCellVolumetricChange 0.01   // config/constant_defaults.h:157-173
+#define MaxCellSurfaceAreaChange 0.09
+#define MaxCellBendingAngle 0.0555
+#define MaxPLTBendingAngle 2.467
+#define MaxCellPersistenceLength 9.0
+#define FORCE_LIMIT_PN 50.0
+
+constexpr int MD = CellTables::MAXD;
+
+__device__ __forceinline__ double norm3(double a, double b, double c) { double r = 0.0; r += a * a; r += b * b; r += c * c; return sqrt(r); }
+__device__ __forceinline__ double dot3(double a0, double a1, double a2, double b0, double b1, double b2) { double r = 0.0; r += a0 * b0; r += a1 * b1; r += a2 * b2; return r; }
+
+// one workgroup = one cell.  LDS: positions, per-triangle {volume term, area, unit normal, area-force
+// magnitude}, per-vertex bending vector (RBC) or per-edge {link, visc, bending} vectors (PLT).
+template <int MODEL, bool SEPARATE>
+__global__ __launch_bounds__(256) void mechanics_kernel(MechArgs m) {
+  extern __shared__ double lds[];
+  const int nv = m.nv, nt = m.nt, ne = m.ne;
+  double *xs = lds, *ys = xs + nv, *zs = ys + nv;
+  double *tV = zs + nv, *tA = tV + nt, *tNx = tA + nt, *tNy = tNx + nt, *tNz = tNy + nt, *tAfm = tNz + nt;
+  double *ex = tAfm + nt;  // RBC: B[3][nv]; PLT: edge vectors [9][ne]
+  __shared__ double s_volume_force;
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const long base = (long)blockIdx.x * nv;
+
+  for (int i = tid; i < nv; i += nth) { xs[i] = m.px[base + i]; ys[i] = m.py[base + i]; zs[i] = m.pz[base + i]; }
+  __syncthreads();
+
+  // ---- per-triangle quantities (rbcHighOrderModel.cpp:56-98 / pltSimpleModel.cpp:57-99)
+  for (int t = tid; t < nt; t += nth) {
+    const int i0 = m.tri[3 * t], i1 = m.tri[3 * t + 1], i2 = m.tri[3 * t + 2];
+    const double v0x = xs[i0], v0y = ys[i0], v0z = zs[i0], v1x = xs[i1], v1y = ys[i1], v1z = zs[i1], v2x = xs[i2], v2y = ys[i2], v2z = zs[i2];
+    const double v210 = v2x * v1y * v0z, v120 = v1x * v2y * v0z, v201 = v2x * v0y * v1z;
+    const double v021 = v0x * v2y * v1z, v102 = v1x * v0y * v2z, v012 = v0x * v1y * v2z;
+    tV[t] = (-v210 + v120 + v201 - v021 - v102 + v012);
+    const double e1x = v1x - v0x, e1y = v1y - v0y, e1z = v1z - v0z, e2x = v2x - v0x, e2y = v2y - v0y, e2z = v2z - v0z;
+    double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+    const double nn = norm3(nx, ny, nz);
+    double area;
+    if (nn != 0.0) { area = 0.5 * nn; nx /= nn; ny /= nn; nz /= nn; } else { area = 0.0; nx = ny = nz = 0.0; }
+    tA[t] = area; tNx[t] = nx; tNy[t] = ny; tNz[t] = nz;
+    const double aeq = m.tri_area_eq[t];
+    const double areaRatio = (area - aeq) / aeq;
+    tAfm[t] = m.k_area * (areaRatio + areaRatio / fabs(MaxCellSurfaceAreaChange - areaRatio * areaRatio));
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // the reference accumulates the signed-volume terms sequentially in triangle order; do the same so
+    // that every copy of a cell (other GPUs, the CPU oracle) gets the same bits
+    double volume = 0.0;
+    for (int t = 0; t < nt; t++) volume += tV[t];
+    volume *= (1.0 / 6.0);
+    const double vf = (volume - m.volume_eq) / m.volume_eq;
+    s_volume_force = -m.k_volume * vf / fabs(MaxCellVolumetricChange - vf * vf);
+  }
+
+  if (MODEL == HC_MODEL_RBC_HO) {
+    // ---- per-vertex bending vector (rbcHighOrderModel.cpp:127-160)
+    double *Bx = ex, *By = ex + nv, *Bz = ex + 2 * nv;
+    for (int i = tid; i < nv; i += nth) {
+      const int nn = m.nring[i];
+      const double x = xs[i], y = ys[i], z = zs[i];
+      double sx = 0., sy = 0., sz = 0.;
+      for (int j = 0; j < nn; j++) { const int r = m.ring[6 * i + j]; sx += xs[r]; sy += ys[r]; sz += zs[r]; }
+      const double dvx = sx / nn - x, dvy = sy / nn - y, dvz = sz / nn - z;
+      double pnx = 0., pny = 0., pnz = 0.;
+      for (int j = 0; j < nn; j++) {
+        const int ra = m.ring[6 * i + j], rb = m.ring[6 * i + (j + 1 == nn ? 0 : j + 1)];
+        const double ax = xs[ra] - x, ay = ys[ra] - y, az = zs[ra] - z, bx = xs[rb] - x, by = ys[rb] - y, bz = zs[rb] - z;
+        double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+        const double l = norm3(cx, cy, cz);
+        cx /= l; cy /= l; cz /= l;
+        pnx += cx; pny += cy; pnz += cz;
+      }
+      const double l = norm3(pnx, pny, pnz);
+      pnx /= l; pny /= l; pnz /= l;
+      const double ndev = dot3(pnx, pny, pnz, dvx, dvy, dvz);
+      const double dDev = (ndev - m.patch_eq[i]) / m.edge_mean_eq;
+      const double mag = m.k_bend * (dDev + dDev / fabs(MaxCellBendingAngle - dDev * dDev));
+      Bx[i] = mag * pnx; By[i] = mag * pny; Bz[i] = mag * pnz;
+    }
+  } else {
+    // ---- per-edge vectors (pltSimpleModel.cpp:120-183): link, viscosity, dihedral bending
+    double *Lx = ex, *Ly = ex + ne, *Lz = ex + 2 * ne, *Vx = ex + 3 * ne, *Vy = ex + 4 * ne, *Vz = ex + 5 * ne,
+           *Gx = ex + 6 * ne, *Gy = ex + 7 * ne, *Gz = ex + 8 * ne;
+    for (int e = tid; e < ne; e += nth) {
+      const int e0 = m.edge[2 * e], e1 = m.edge[2 * e + 1];
+      const double evx = xs[e1] - xs[e0], evy = ys[e1] - ys[e0], evz = zs[e1] - zs[e0];
+      const double el = sqrt(evx * evx + evy * evy + evz * evz);
+      const double ux = evx / el, uy = evy / el, uz = evz / el;
+      const double leq = m.edge_len_eq[e];
+      const double ef = (el - leq) / leq;
+      const double fs = m.k_link * (ef + ef / fabs(MaxCellPersistenceLength - ef * ef));
+      Lx[e] = ux * fs; Ly[e] = uy * fs; Lz[e] = uz * fs;
+      const double rvx = m.vx[base + e1] - m.vx[base + e0], rvy = m.vy[base + e1] - m.vy[base + e0], rvz = m.vz[base + e1] - m.vz[base + e0];
+      const double pr = dot3(rvx, rvy, rvz, ux, uy, uz);
+      double wx = m.eta_m * (pr * ux), wy = m.eta_m * (pr * uy), wz = m.eta_m * (pr * uz);
+      const double wm = norm3(wx, wy, wz);
+      if (wm > FORCE_LIMIT_PN / 4.0) { const double sc = (FORCE_LIMIT_PN / 4.0) / wm; wx *= sc; wy *= sc; wz *= sc; }
+      Vx[e] = wx; Vy[e] = wy; Vz[e] = wz;
+      const int b0 = m.ebt[2 * e], b1 = m.ebt[2 * e + 1];
+      const double a = tNx[b0] + tNx[b1], b = tNy[b0] + tNy[b1], c = tNz[b0] + tNz[b1];
+      // getAngleBetweenFaces (helper/geometryUtils.h:49-52)
+      const double crx = tNy[b0] * tNz[b1] - tNz[b0] * tNy[b1], cry = tNz[b0] * tNx[b1] - tNx[b0] * tNz[b1], crz = tNx[b0] * tNy[b1] - tNy[b0] * tNx[b1];
+      const double angle = atan2(dot3(crx, cry, crz, ux, uy, uz), dot3(tNx[b0], tNy[b0], tNz[b0], tNx[b1], tNy[b1], tNz[b1]));
+      const double af = angle - m.edge_angle_eq[e];
+      const double fm = m.k_bend * (af + af / fabs(MaxPLTBendingAngle - af * af));
+      Gx[e] = (fm * a) * 0.5; Gy[e] = (fm * b) * 0.5; Gz[e] = (fm * c) * 0.5;
+    }
+  }
+  __syncthreads();
+  const double volume_force = s_volume_force;
+
+  // ---- per-vertex gather in the reference's accumulation order
+  for (int i = tid; i < nv; i += nth) {
+    // components: 0 volume, 1 area, 2 bending, 3 link, 4 visc, 5 inner link; unified mode uses slot 0 only
+    double acc[SEPARATE ? 6 : 1][3];
+#pragma unroll
+    for (int c = 0; c < (SEPARATE ? 6 : 1); c++) acc[c][0] = acc[c][1] = acc[c][2] = 0.0;
+#define ACC(C) acc[SEPARATE ? (C) : 0]
+    const double x = xs[i], y = ys[i], z = zs[i];
+    for (int k = 0; k < MD; k++) {  // area force, triangle order
+      const int t = m.vtri[MD * i + k];
+      if (t < 0) break;
+      const int i0 = m.tri[3 * t], i1 = m.tri[3 * t + 1], i2 = m.tri[3 * t + 2];
+      const double cx = (xs[i0] + xs[i1] + xs[i2]) / 3.0, cy = (ys[i0] + ys[i1] + ys[i2]) / 3.0, cz = (zs[i0] + zs[i1] + zs[i2]) / 3.0;
+      const double afm = tAfm[t];
+      ACC(1)[0] += afm * (cx - x); ACC(1)[1] += afm * (cy - y); ACC(1)[2] += afm * (cz - z);
+    }
+    for (int k = 0; k < MD; k++) {  // volume force, triangle order (rbcHighOrderModel.cpp:107-113)
+      const int t = m.vtri[MD * i + k];
+      if (t < 0) break;
+      const double sc = tA[t] / m.area_mean_eq;
+      ACC(0)[0] += (volume_force * tNx[t]) * sc; ACC(0)[1] += (volume_force * tNy[t]) * sc; ACC(0)[2] += (volume_force * tNz[t]) * sc;
+    }
+    if (MODEL == HC_MODEL_RBC_HO) {
+      const double *Bx = ex, *By = ex + nv, *Bz = ex + 2 * nv;
+      for (int k = 0; k < MD; k++) {  // bending: own vector, or -B/n of a ring neighbour, ascending source id
+        const int src = m.bsrc[MD * i + k];
+        if (src < 0) break;
+        if (src == i) { ACC(2)[0] += Bx[i]; ACC(2)[1] += By[i]; ACC(2)[2] += Bz[i]; }
+        else { const int nn = m.nring[src]; ACC(2)[0] += -Bx[src] / nn; ACC(2)[1] += -By[src] / nn; ACC(2)[2] += -Bz[src] / nn; }
+      }
+      for (int k = 0; k < MD; k++) {  // links (rbcHighOrderModel.cpp:169-204)
+        const int e = m.vedge[MD * i + k];
+        if (e < 0) break;
+        const int e0 = m.edge[2 * e], e1 = m.edge[2 * e + 1];
+        const double evx = xs[e1] - xs[e0], evy = ys[e1] - ys[e0], evz = zs[e1] - zs[e0];
+        const double el = norm3(evx, evy, evz);
+        const double ux = evx / el, uy = evy / el, uz = evz / el;
+        const double leq = m.edge_len_eq[e];
+        const double ef = (el - leq) / leq;
+        const double fs = m.k_link * (ef + ef / fabs(MaxCellPersistenceLength - ef * ef));
+        const double frx = ux * fs, fry = uy * fs, frz = uz * fs;
+        const bool first = m.vedge_s[MD * i + k] > 0;
+        if (first) { ACC(3)[0] += frx; ACC(3)[1] += fry; ACC(3)[2] += frz; } else { ACC(3)[0] -= frx; ACC(3)[1] -= fry; ACC(3)[2] -= frz; }
+        if (m.eta_m != 0.0) {
+          const double rvx = m.vx[base + e1] - m.vx[base + e0], rvy = m.vy[base + e1] - m.vy[base + e0], rvz = m.vz[base + e1] - m.vz[base + e0];
+          const double pr = dot3(rvx, rvy, rvz, ux, uy, uz);
+          double wx = m.eta_m * (pr * ux), wy = m.eta_m * (pr * uy), wz = m.eta_m * (pr * uz);
+          const double wm = norm3(wx, wy, wz);
+          if (wm > FORCE_LIMIT_PN / 4.0) { const double sc = (FORCE_LIMIT_PN / 4.0) / wm; wx *= sc; wy *= sc; wz *= sc; }
+          if (first) { ACC(4)[0] += wx; ACC(4)[1] += wy; ACC(4)[2] += wz; } else { ACC(4)[0] -= wx; ACC(4)[1] -= wy; ACC(4)[2] -= wz; }
+        }
+      }
+    } else {
+      const double *Lx = ex, *Ly = ex + ne, *Lz = ex + 2 * ne, *Vx = ex + 3 * ne, *Vy = ex + 4 * ne, *Vz = ex + 5 * ne,
+                   *Gx = ex + 6 * ne, *Gy = ex + 7 * ne, *Gz = ex + 8 * ne;
+      // merge of the vertex's own edges and the edges it is an outer point of, ascending edge id
+      int ka = 0, kb = 0;
+      while (true) {
+        const int ea = ka < MD ? m.vedge[MD * i + ka] : -1, eb = kb < MD ? m.vouter[MD * i + kb] : -1;
+        if (ea < 0 && eb < 0) break;
+        if (eb < 0 || (ea >= 0 && ea < eb)) {
+          const bool first = m.vedge_s[MD * i + ka] > 0;
+          if (first) { ACC(3)[0] += Lx[ea]; ACC(3)[1] += Ly[ea]; ACC(3)[2] += Lz[ea]; ACC(4)[0] += Vx[ea]; ACC(4)[1] += Vy[ea]; ACC(4)[2] += Vz[ea]; }
+          else { ACC(3)[0] -= Lx[ea]; ACC(3)[1] -= Ly[ea]; ACC(3)[2] -= Lz[ea]; ACC(4)[0] -= Vx[ea]; ACC(4)[1] -= Vy[ea]; ACC(4)[2] -= Vz[ea]; }
+          ACC(2)[0] += Gx[ea]; ACC(2)[1] += Gy[ea]; ACC(2)[2] += Gz[ea];
+          ka++;
+        } else {
+          ACC(2)[0] -= Gx[eb]; ACC(2)[1] -= Gy[eb]; ACC(2)[2] -= Gz[eb];
+          kb++;
+        }
+      }
+      for (int k = 0; k < MD; k++) {  // inner links (pltSimpleModel.cpp:186-205)
+        const int e = m.vinner[MD * i + k];
+        if (e < 0) break;
+        const int e0 = m.iedge[2 * e], e1 = m.iedge[2 * e + 1];
+        const double evx = xs[e1] - xs[e0], evy = ys[e1] - ys[e0], evz = zs[e1] - zs[e0];
+        const double el = sqrt(evx * evx + evy * evy + evz * evz);
+        const double ux = evx / el, uy = evy / el, uz = evz / el;
+        const double leq = m.iedge_len_eq[e];
+        const double ef = (el - leq) / leq;
+        const double fs = m.k_link * 5.0 * ef;
+        if (m.vinner_s[MD * i + k] > 0) { ACC(5)[0] += ux * fs; ACC(5)[1] += uy * fs; ACC(5)[2] += uz * fs; }
+        else { ACC(5)[0] -= ux * fs; ACC(5)[1] -= uy * fs; ACC(5)[2] -= uz * fs; }
+      }
+    }
+#undef ACC
+    if (SEPARATE) {
+#pragma unroll
+      for (int c = 0; c < 6; c++)
+        for (int d = 0; d < 3; d++) m.comp[((long)c * m.ncv + base + i) * 3 + d] = acc[c][d];
+    } else {
+      m.fx[base + i] = acc[0][0]; m.fy[base + i] = acc[0][1]; m.fz[base + i] = acc[0][2];
+    }
+  }
+}
+
+// per-cell volume / area / bbox / centroid (helper/cellInfo.cpp:39-80,140-180)
+__global__ __launch_bounds__(256) void cell_info_kernel(int nv, int nt, const int *tri, const double *px, const double *py, const double *pz,
+                                                        double *volume, double *area, double *bbox, double *centroid) {
+  __shared__ double red[256][11];
+  const int tid = threadIdx.x;
+  const long base = (long)blockIdx.x * nv;
+  double vol = 0, ar = 0, lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, cs[3] = {0, 0, 0};
+  for (int t = tid; t < nt; t += 256) {
+    const long i0 = base + tri[3 * t], i1 = base + tri[3 * t + 1], i2 = base + tri[3 * t + 2];
+    const double v0x = px[i0], v0y = py[i0], v0z = pz[i0], v1x = px[i1], v1y = py[i1], v1z = pz[i1], v2x = px[i2], v2y = py[i2], v2z = pz[i2];
+    vol += (-v2x * v1y * v0z + v1x * v2y * v0z + v2x * v0y * v1z - v0x * v2y * v1z - v1x * v0y * v2z + v0x * v1y * v2z);
+    const double e1x = v1x - v0x, e1y = v1y - v0y, e1z = v1z - v0z, e2x = v2x - v0x, e2y = v2y - v0y, e2z = v2z - v0z;
+    const double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+    ar += 0.5 * sqrt(nx * nx + ny * ny + nz * nz);
+  }
+  for (int i = tid; i < nv; i += 256) {
+    const double p[3] = {px[base + i], py[base + i], pz[base + i]};
+    for (int d = 0; d < 3; d++) { lo[d] = fmin(lo[d], p[d]); hi[d] = fmax(hi[d], p[d]); cs[d] += p[d]; }
+  }
+  red[tid][0] = vol; red[tid][1] = ar;
+  for (int d = 0; d < 3; d++) { red[tid][2 + d] = lo[d]; red[tid][5 + d] = hi[d]; red[tid][8 + d] = cs[d]; }
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      red[tid][0] += red[tid + s][0]; red[tid][1] += red[tid + s][1];
+      for (int d = 0; d < 3; d++) {
+        red[tid][2 + d] = fmin(red[tid][2 + d], red[tid + s][2 + d]);
+        red[tid][5 + d] = fmax(red[tid][5 + d], red[tid + s][5 + d]);
+        red[tid][8 + d] += red[tid + s][8 + d];
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const long c = blockIdx.x;
+    volume[c] = red[0][0] / 6.0; area[c] = red[0][1];
+    // bbox order x0 x1 y0 y1 z0 z1 (helper/cellInfo.cpp:148-160)
+    for (int d = 0; d < 3; d++) { bbox[6 * c + 2 * d] = red[0][2 + d]; bbox[6 * c + 2 * d + 1] = red[0][5 + d]; centroid[3 * c + d] = red[0][8 + d] / nv; }
+  }
+}
+
+__global__ void add_vertex_force_kernel(int n, const long *idx, const double *f, double *fx, double *fy, double *fz) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long v = idx[i];
+  fx[v] += f[3 * i]; fy[v] += f[3 * i + 1]; fz[v] += f[3 * i + 2];
+}
+
+__global__ void fill_vert_cell_kernel(long n, int nv, int cell0, long first, int *vert_cell) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  vert_cell[first + i] = cell0 + (int)(i / nv);
+}
+
+// ----------------------------------------------------------------------------
+template <typename T>
+int upload_vec(T **dst, const std::vector<T> &src) {
+  *dst = nullptr;
+  const size_t n = src.size() ? src.size() : 1;
+  HC_HIP(hipMalloc((void **)dst, n * sizeof(T)));
+  if (src.size()) HC_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return HC_OK;
+}
+template <size_t N>
+std::vector<int> flatten(const std::vector<std::array<long, N>> &v) {
+  std::vector<int> o; o.reserve(v.size() * N);
+  for (auto &a : v) for (long x : a) o.push_back((int)x);
+  return o;
+}
+
+}  // namespace
+
+static int free_device_arrays(hc_cells *C) {
+  for (int d = 0; d < 3; d++) {
+    if (C->pos[d]) hipFree(C->pos[d]);
+    if (C->vel[d]) hipFree(C->vel[d]);
+    if (C->frc[d]) hipFree(C->frc[d]);
+    C->pos[d] = C->vel[d] = C->frc[d] = nullptr;
+  }
+  if (C->d_tag) hipFree(C->d_tag);
+  C->d_tag = nullptr; C->cap = 0; C->tag_cap = 0;
+  if (C->d_vert_cell) hipFree(C->d_vert_cell);
+  C->d_vert_cell = nullptr;
+  return HC_OK;
+}
+
+// host staging -> device (after placement, upload or a deletion)
+static int sync_to_device(hc_cells *C) {
+  if (!C->host_dirty) return HC_OK;
+  long nverts = 0, ncells = 0;
+  for (int t = 0; t < C->ntypes; t++) {
+    C->first[t] = nverts;
+    C->ncells[t] = (long)C->hids[t].size();
+    nverts += C->ncells[t] * C->types[t]->host.nv;
+    ncells += C->ncells[t];
+  }
+  if (nverts > C->cap) {
+    free_device_arrays(C);
+    C->cap = nverts + nverts / 8 + 1024;
+    for (int d = 0; d < 3; d++) {
+      HC_HIP(hipMalloc((void **)&C->pos[d], C->cap * sizeof(double)));
+      HC_HIP(hipMalloc((void **)&C->vel[d], C->cap * sizeof(double)));
+      HC_HIP(hipMalloc((void **)&C->frc[d], C->cap * sizeof(double)));
+    }
+    HC_HIP(hipMalloc((void **)&C->d_vert_cell, C->cap * sizeof(int)));
+  }
+  if (ncells + 1 > C->tag_cap) {
+    if (C->d_tag) HC_HIP(hipFree(C->d_tag));
+    C->tag_cap = ncells + ncells / 8 + 64;
+    HC_HIP(hipMalloc((void **)&C->d_tag, C->tag_cap * sizeof(int)));
+  }
+  C->nverts = nverts;
+  std::vector<double> tmp;
+  long cell0 = 0;
+  for (int t = 0; t < C->ntypes; t++) {
+    const long n = C->ncells[t] * C->types[t]->host.nv;
+    if (n == 0) continue;
+    std::vector<double> *src[3] = {&C->hpos[t], &C->hvel[t], &C->hfrc[t]};
+    double **dst[3] = {C->pos, C->vel, C->frc};
+    tmp.resize((size_t)n);
+    for (int w = 0; w < 3; w++)
+      for (int d = 0; d < 3; d++) {
+        for (long i = 0; i < n; i++) tmp[(size_t)i] = (*src[w])[(size_t)(3 * i + d)];
+        HC_HIP(hipMemcpy(dst[w][d] + C->first[t], tmp.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+      }
+    hipLaunchKernelGGL(fill_vert_cell_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), n, C->types[t]->host.nv, (int)cell0, C->first[t], C->d_vert_cell);
+    HC_HIP(hipGetLastError());
+    cell0 += C->ncells[t];
+  }
+  HC_HIP(hipMemsetAsync(C->d_tag, 0, C->tag_cap * sizeof(int), hc::stream()));
+  HC_HIP(hipStreamSynchronize(hc::stream()));
+  C->host_dirty = false;
+  return HC_OK;
+}
+
+// device -> host staging (before host-side edits)
+static int sync_to_host(hc_cells *C) {
+  if (C->host_dirty) return HC_OK;  // host already authoritative
+  HC_HIP(hipStreamSynchronize(hc::stream()));
+  std::vector<double> tmp;
+  for (int t = 0; t < C->ntypes; t++) {
+    const long n = C->ncells[t] * C->types[t]->host.nv;
+    std::vector<double> *dstv[3] = {&C->hpos[t], &C->hvel[t], &C->hfrc[t]};
+    double **src[3] = {C->pos, C->vel, C->frc};
+    tmp.resize((size_t)n);
+    for (int w = 0; w < 3; w++) {
+      dstv[w]->resize((size_t)(3 * n));
+      for (int d = 0; d < 3; d++) {
+        if (n) HC_HIP(hipMemcpy(tmp.data(), src[w][d] + C->first[t], (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        for (long i = 0; i < n; i++) (*dstv[w])[(size_t)(3 * i + d)] = tmp[(size_t)i];
+      }
+    }
+  }
+  return HC_OK;
+}
+
+static MechArgs mech_args(const hc_cells *C, int t) {
+  const hc_celltype *T = C->types[t];
+  MechArgs m;
+  m.model = T->host.model; m.nv = T->host.nv; m.nt = T->host.nt; m.ne = T->host.ne; m.nie = T->host.nie;
+  m.tri = T->d_tri; m.edge = T->d_edge; m.ebt = T->d_ebt; m.ebo = T->d_ebo; m.iedge = T->d_iedge;
+  m.vtri = T->d_vtri; m.vtri_k = T->d_vtri_k; m.vedge = T->d_vedge; m.vedge_s = T->d_vedge_s; m.bsrc = T->d_bsrc;
+  m.vouter = T->d_vouter; m.vinner = T->d_vinner; m.vinner_s = T->d_vinner_s; m.ring = T->d_ring; m.nring = T->d_nring;
+  m.tri_area_eq = T->d_tri_area_eq; m.edge_len_eq = T->d_edge_len_eq; m.edge_angle_eq = T->d_edge_angle_eq;
+  m.patch_eq = T->d_patch_eq; m.iedge_len_eq = T->d_iedge_len_eq;
+  m.volume_eq = T->host.volume_eq; m.area_mean_eq = T->host.area_mean_eq; m.edge_mean_eq = T->host.edge_mean_eq;
+  m.k_volume = T->host.k_volume; m.k_area = T->host.k_area; m.k_link = T->host.k_link; m.k_bend = T->host.k_bend; m.eta_m = T->host.eta_m;
+  const long f = C->first[t];
+  m.px = C->pos[0] + f; m.py = C->pos[1] + f; m.pz = C->pos[2] + f;
+  m.vx = C->vel[0] + f; m.vy = C->vel[1] + f; m.vz = C->vel[2] + f;
+  m.fx = C->frc[0] + f; m.fy = C->frc[1] + f; m.fz = C->frc[2] + f;
+  m.comp = nullptr; m.ncv = C->ncells[t] * T->host.nv;
+  return m;
+}
+
+static size_t mech_lds_bytes(const CellTables &T) {
+  const size_t extra = T.model == HC_MODEL_RBC_HO ? 3 * (size_t)T.nv : 9 * (size_t)T.ne;
+  return (3 * (size_t)T.nv + 6 * (size_t)T.nt + extra) * sizeof(double);
+}
+
+static int launch_mechanics(hc_cells *C, int t, double *comp) {
+  if (C->ncells[t] == 0) return HC_OK;
+  MechArgs m = mech_args(C, t);
+  m.comp = comp;
+  const CellTables &T = C->types[t]->host;
+  const size_t lds = mech_lds_bytes(T);
+  HC_REQUIRE(lds <= 160 * 1024 - 64, "mechanics: cell type does not fit the 160 KiB LDS of a CU");
+  const int threads = T.nv > 128 ? 256 : 128;
+  const dim3 grid((unsigned)C->ncells[t]);
+#define LAUNCH(MODEL, SEP)                                                                                        \
+  do {                                                                                                            \
+    HC_HIP(hipFuncSetAttribute((const void *)mechanics_kernel<MODEL, SEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((mechanics_kernel<MODEL, SEP>), grid, dim3(threads), lds, hc::stream(), m);                \
+  } while (0)
+  if (T.model == HC_MODEL_RBC_HO) { if (comp) LAUNCH(HC_MODEL_RBC_HO, true); else LAUNCH(HC_MODEL_RBC_HO, false); }
+  else { if (comp) LAUNCH(HC_MODEL_PLT_SIMPLE, true); else LAUNCH(HC_MODEL_PLT_SIMPLE, false); }
+#undef LAUNCH
+  HC_HIP(hipGetLastError());
+  return HC_OK;
+}
+
+extern "C" {
+
+int hcp_celltype_create(hc_celltype **out, int model, int shape, const hc_params *P, const hc_material *M) {
+  HC_REQUIRE(out && P && M, "hcp_celltype_create: null pointer");
+  if (hc::stream() == nullptr) { hc::set_error("hcp_celltype_create: hc_init() has not been called"); return HC_ERR_STATE; }
+  hc_celltype *T = new hc_celltype();
+  std::string err = build_cell_tables(T->host, model, shape, *P, *M);
+  if (!err.empty()) { delete T; hc::set_error("hcp_celltype_create: " + err); return HC_ERR_ARG; }
+  const CellTables &H = T->host;
+  int rc = HC_OK;
+  auto up_i = [&](int **d, const std::vector<int> &v) { if (rc == HC_OK) rc = upload_vec(d, v); };
+  auto up_d = [&](double **d, const std::vector<double> &v) { if (rc == HC_OK) rc = upload_vec(d, v); };
+  up_i(&T->d_tri, flatten(H.triangles)); up_i(&T->d_edge, flatten(H.edges));
+  up_i(&T->d_ebt, flatten(H.edge_bending_triangles)); up_i(&T->d_ebo, flatten(H.edge_bending_outer));
+  up_i(&T->d_iedge, flatten(H.inner_edges));
+  up_i(&T->d_vtri, H.vtri); up_i(&T->d_vtri_k, H.vtri_k); up_i(&T->d_vedge, H.vedge); up_i(&T->d_vedge_s, H.vedge_s);
+  up_i(&T->d_bsrc, H.bsrc); up_i(&T->d_vouter, H.vouter); up_i(&T->d_vinner, H.vinner); up_i(&T->d_vinner_s, H.vinner_s);
+  up_i(&T->d_ring, flatten(H.vertex_vertexes)); up_i(&T->d_nring, H.vertex_n_vertexes);
+  up_d(&T->d_tri_area_eq, H.triangle_area_eq); up_d(&T->d_edge_len_eq, H.edge_length_eq);
+  up_d(&T->d_edge_angle_eq, H.edge_angle_eq); up_d(&T->d_patch_eq, H.patch_dist_eq); up_d(&T->d_iedge_len_eq, H.inner_edge_length_eq);
+  if (rc != HC_OK) return rc;
+  *out = T;
+  return HC_OK;
+}
+
+int hcp_celltype_destroy(hc_celltype *T) {
+  if (!T) return HC_OK;
+  int *ip[] = {T->d_tri, T->d_edge, T->d_ebt, T->d_ebo, T->d_iedge, T->d_vtri, T->d_vtri_k, T->d_vedge, T->d_vedge_s, T->d_bsrc,
+               T->d_vouter, T->d_vinner, T->d_vinner_s, T->d_ring, T->d_nring};
+  double *dp[] = {T->d_tri_area_eq, T->d_edge_len_eq, T->d_edge_angle_eq, T->d_patch_eq, T->d_iedge_len_eq};
+  for (int *p : ip) if (p) hipFree(p);
+  for (double *p : dp) if (p) hipFree(p);
+  delete T;
+  return HC_OK;
+}
+
+int hcp_celltype_sizes(const hc_celltype *T, int out[4]) {
+  HC_REQUIRE(T && out, "hcp_celltype_sizes: null pointer");
+  out[0] = T->host.nv; out[1] = T->host.nt; out[2] = T->host.ne; out[3] = T->host.nie;
+  return HC_OK;
+}
+
+int hcp_celltype_tables(const hc_celltype *T, double *vertices, long *triangles, long *edges, double *edge_length_eq,
+                        double *edge_angle_eq, double *triangle_area_eq, long *vertex_vertexes, double *patch_dist_eq,
+                        double scalars[9]) {
+  HC_REQUIRE(T, "hcp_celltype_tables: null cell type");
+  const CellTables &H = T->host;
+  if (vertices) for (int i = 0; i < H.nv; i++) for (int d = 0; d < 3; d++) vertices[3 * i + d] = H.vertices[i][d];
+  if (triangles) for (int i = 0; i < H.nt; i++) for (int d = 0; d < 3; d++) triangles[3 * i + d] = H.triangles[i][d];
+  if (edges) for (int i = 0; i < H.ne; i++) for (int d = 0; d < 2; d++) edges[2 * i + d] = H.edges[i][d];
+  if (edge_length_eq) std::copy(H.edge_length_eq.begin(), H.edge_length_eq.end(), edge_length_eq);
+  if (edge_angle_eq) std::copy(H.edge_angle_eq.begin(), H.edge_angle_eq.end(), edge_angle_eq);
+  if (triangle_area_eq) std::copy(H.triangle_area_eq.begin(), H.triangle_area_eq.end(), triangle_area_eq);
+  if (vertex_vertexes) for (int i = 0; i < H.nv; i++) for (int d = 0; d < 6; d++) vertex_vertexes[6 * i + d] = H.vertex_vertexes[i][d];
+  if (patch_dist_eq) std::copy(H.patch_dist_eq.begin(), H.patch_dist_eq.end(), patch_dist_eq);
+  if (scalars) {
+    const double s[9] = {H.volume_eq, H.area_mean_eq, H.edge_mean_eq, H.angle_mean_eq, H.k_volume, H.k_area, H.k_link, H.k_bend, H.eta_m};
+    std::copy(s, s + 9, scalars);
+  }
+  return HC_OK;
+}
+
+int hcp_create(hc_cells **out, hc_lattice *L, const hc_params *P) {
+  HC_REQUIRE(out && L && P, "hcp_create: null pointer");
+  hc_cells *C = new hc_cells();
+  C->L = L; C->P = *P;
+  HC_HIP(hipHostMalloc((void **)&C->h_ntag, sizeof(int), hipHostMallocDefault));
+  *C->h_ntag = 0;
+  HC_HIP(hipMalloc((void **)&C->d_ntag, sizeof(int)));
+  HC_HIP(hipMemset(C->d_ntag, 0, sizeof(int)));
+  *out = C;
+  return HC_OK;
+}
+
+int hcp_destroy(hc_cells *C) {
+  if (!C) return HC_OK;
+  hipStreamSynchronize(hc::stream());
+  free_device_arrays(C);
+  if (C->h_ntag) hipHostFree(C->h_ntag);
+  if (C->d_ntag) hipFree(C->d_ntag);
+  delete C;
+  return HC_OK;
+}
+
+int hcp_add_type(hc_cells *C, hc_celltype *T, int material_timescale, int *type_index) {
+  HC_REQUIRE(C && T, "hcp_add_type: null pointer");
+  HC_REQUIRE(C->ntypes < 8, "hcp_add_type: at most 8 cell types");
+  HC_REQUIRE(material_timescale >= 1, "hcp_add_type: material timescale must be >= 1");
+  C->types[C->ntypes] = T; C->timescale[C->ntypes] = material_timescale;
+  if (type_index) *type_index = C->ntypes;
+  C->ntypes++;
+  return HC_OK;
+}
+
+int hcp_add_cell(hc_cells *C, int type, long cell_id, const double centre_lu[3], const double angles[3], double min_dist_um, int *placed) {
+  HC_REQUIRE(C && centre_lu && angles, "hcp_add_cell: null pointer");
+  HC_REQUIRE(type >= 0 && type < C->ntypes, "hcp_add_cell: unknown cell type");
+  int rc = sync_to_host(C); if (rc != HC_OK) return rc;
+  const CellTables &T = C->types[type]->host;
+  const hc_lattice *L = C->L;
+  const int nv = T.nv;
+  // centre the mesh on its bounding box, rotate about that centre (X, Y, Z order), translate
+  // (io/readPositionsBloodCells.cpp:113-123, :316-318, :349)
+  auto bbox_centre = [&](const std::vector<Vec3> &v) {
+    Vec3 lo = v[0], hi = v[0];
+    for (auto &p : v) for (int d = 0; d < 3; d++) { lo[d] = std::min(lo[d], p[d]); hi[d] = std::max(hi[d], p[d]); }
+    return Vec3{(hi[0] + lo[0]) * 0.5, (hi[1] + lo[1]) * 0.5, (hi[2] + lo[2]) * 0.5};
+  };
+  std::vector<Vec3> m = T.vertices;
+  const Vec3 c0 = bbox_centre(m);
+  for (auto &p : m) for (int d = 0; d < 3; d++) p[d] -= c0[d];
+  const Vec3 mc = bbox_centre(m);
+  double R[3][3];
+  rotation_matrix_xyz(angles[0], angles[1], angles[2], R);
+  for (auto &p : m) {
+    const Vec3 x{p[0] + -1.0 * mc[0], p[1] + -1.0 * mc[1], p[2] + -1.0 * mc[2]};
+    for (int a = 0; a < 3; a++) { double s = 0; for (int b = 0; b < 3; b++) s += R[a][b] * x[b]; p[a] = s + mc[a]; }
+  }
+  // rejection test against the (host copy of the) mask, :139-164
+  const std::vector<uint8_t> &mask = L->hmask;
+  auto is_boundary = [&](long gx, long gy, long gz) -> bool {
+    long lx = gx - L->x0, ly = gy, lz = gz;
+    if (L->n_slabs == 1) { if (lx < 0 || lx >= L->nx) { if (L->periodic[0]) lx = ((lx % L->nx) + L->nx) % L->nx; else return false; } }
+    else if (lx < -HALO || lx >= L->nx + HALO) return false;
+    if (ly < 0 || ly >= L->ny) { if (L->periodic[1]) ly = ((ly % L->ny) + L->ny) % L->ny; else return false; }
+    if (lz < 0 || lz >= L->nz) { if (L->periodic[2]) lz = ((lz % L->nz) + L->nz) % L->nz; else return false; }
+    return mask[(size_t)(lx + HALO) * L->plane + (size_t)ly * L->nz + lz] != 0;
+  };
+  const int deny = (int)((min_dist_um * 1e-6) / C->P.dx);
+  bool ok = true;
+  for (int i = 0; i < nv && ok; i++) {
+    const double v[3] = {centre_lu[0] + m[i][0], centre_lu[1] + m[i][1], centre_lu[2] + m[i][2]};
+    const long n[3] = {(int)(v[0] + 0.5), (int)(v[1] + 0.5), (int)(v[2] + 0.5)};
+    if (is_boundary(n[0], n[1], n[2])) { ok = false; break; }
+    for (int a = -deny; a <= deny && ok; a++) for (int b = -deny; b <= deny && ok; b++) for (int c = -deny; c <= deny; c++)
+      if (is_boundary(n[0] + a, n[1] + b, n[2] + c)) { ok = false; break; }
+  }
+  if (placed) *placed = ok ? 1 : 0;
+  if (!ok) return HC_OK;
+  for (int i = 0; i < nv; i++) {
+    for (int d = 0; d < 3; d++) { C->hpos[type].push_back(centre_lu[d] + m[i][d]); C->hvel[type].push_back(0.0); C->hfrc[type].push_back(0.0); }
+  }
+  C->hids[type].push_back(cell_id);
+  C->host_dirty = true;
+  return HC_OK;
+}
+
+int hcp_counts(const hc_cells *C, long *n_vertices, long *n_cells, long *n_deleted) {
+  HC_REQUIRE(C, "hcp_counts: null pointer");
+  long nv = 0, nc = 0;
+  for (int t = 0; t < C->ntypes; t++) { nc += (long)C->hids[t].size(); nv += (long)C->hids[t].size() * C->types[t]->host.nv; }
+  if (n_vertices) *n_vertices = nv;
+  if (n_cells) *n_cells = nc;
+  if (n_deleted) *n_deleted = C->n_deleted;
+  return HC_OK;
+}
+
+int hcp_type_range(const hc_cells *C, int type, long *first_vertex, long *n_cells) {
+  HC_REQUIRE(C && type >= 0 && type < C->ntypes, "hcp_type_range: bad arguments");
+  long f = 0;
+  for (int t = 0; t < type; t++) f += (long)C->hids[t].size() * C->types[t]->host.nv;
+  if (first_vertex) *first_vertex = f;
+  if (n_cells) *n_cells = (long)C->hids[type].size();
+  return HC_OK;
+}
+
+int hcp_download(hc_cells *C, int what, double *out) {
+  HC_REQUIRE(C && out && what >= 0 && what <= 2, "hcp_download: bad arguments");
+  int rc = sync_to_host(C); if (rc != HC_OK) return rc;
+  size_t o = 0;
+  for (int t = 0; t < C->ntypes; t++) {
+    const std::vector<double> &src = what == 0 ? C->hpos[t] : what == 1 ? C->hvel[t] : C->hfrc[t];
+    std::copy(src.begin(), src.end(), out + o);
+    o += src.size();
+  }
+  return HC_OK;
+}
+
+int hcp_upload(hc_cells *C, int what, const double *in) {
+  HC_REQUIRE(C && in && what >= 0 && what <= 2, "hcp_upload: bad arguments");
+  int rc = sync_to_host(C); if (rc != HC_OK) return rc;
+  size_t o = 0;
+  for (int t = 0; t < C->ntypes; t++) {
+    std::vector<double> &dst = what == 0 ? C->hpos[t] : what == 1 ? C->hvel[t] : C->hfrc[t];
+    std::copy(in + o, in + o + dst.size(), dst.begin());
+    o += dst.size();
+  }
+  C->host_dirty = true;
+  return HC_OK;
+}
+
+int hcp_download_cell_ids(hc_cells *C, long *ids) {
+  HC_REQUIRE(C && ids, "hcp_download_cell_ids: null pointer");
+  size_t o = 0;
+  for (int t = 0; t < C->ntypes; t++) { std::copy(C->hids[t].begin(), C->hids[t].end(), ids + o); o += C->hids[t].size(); }
+  return HC_OK;
+}
+
+int hcp_add_vertex_force(hc_cells *C, const long *vertex_index, int n, const double *f) {
+  HC_REQUIRE(C && vertex_index && f && n >= 0, "hcp_add_vertex_force: bad arguments");
+  if (n == 0) return HC_OK;
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  for (int i = 0; i < n; i++) HC_REQUIRE(vertex_index[i] >= 0 && vertex_index[i] < C->nverts, "hcp_add_vertex_force: vertex index out of range");
+  long *d_idx = nullptr; double *d_f = nullptr;
+  HC_HIP(hipMalloc((void **)&d_idx, n * sizeof(long)));
+  HC_HIP(hipMalloc((void **)&d_f, 3 * n * sizeof(double)));
+  HC_HIP(hipMemcpyAsync(d_idx, vertex_index, n * sizeof(long), hipMemcpyHostToDevice, hc::stream()));
+  HC_HIP(hipMemcpyAsync(d_f, f, 3 * n * sizeof(double), hipMemcpyHostToDevice, hc::stream()));
+  hipLaunchKernelGGL(add_vertex_force_kernel, dim3((n + 255) / 256), dim3(256), 0, hc::stream(), n, (const long *)d_idx, (const double *)d_f, C->frc[0], C->frc[1], C->frc[2]);
+  HC_HIP(hipGetLastError());
+  HC_HIP(hipStreamSynchronize(hc::stream()));
+  hipFree(d_idx); hipFree(d_f);
+  return HC_OK;
+}
+
+int hcp_spread(hc_cells *C, int force_limit) {
+  HC_REQUIRE(C, "hcp_spread: null pointer");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  if (C->nverts == 0) return HC_OK;
+  hc::ProfScope prof(hc::PK_SPREAD);
+  const LatView v = make_view(C->L);
+  hipLaunchKernelGGL(ibm_spread_kernel, dim3((unsigned)((C->nverts + 255) / 256)), dim3(256), 0, hc::stream(), v, C->nverts,
+                     (const double *)C->pos[0], (const double *)C->pos[1], (const double *)C->pos[2], C->frc[0], C->frc[1], C->frc[2],
+                     C->L->force[C->L->fcur], force_limit, C->P.f_limit);
+  HC_HIP(hipGetLastError());
+  return HC_OK;
+}
+
+int hcp_interpolate(hc_cells *C) {
+  HC_REQUIRE(C, "hcp_interpolate: null pointer");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  if (C->nverts == 0) return HC_OK;
+  hc::ProfScope prof(hc::PK_INTERP);
+  const hc_lattice *L = C->L;
+  const LatView v = make_view(L);
+  // state after hcl_step_end: f[cur] holds the populations just written, force[1-fcur] the force they were collided with
+  PopView pv{L->f[L->cur], L->force[1 - L->fcur], L->body[0], L->body[1], L->body[2]};
+  hipLaunchKernelGGL(ibm_interpolate_kernel, dim3((unsigned)((C->nverts + 255) / 256)), dim3(256), 0, hc::stream(), v, pv, C->nverts,
+                     (const double *)C->pos[0], (const double *)C->pos[1], (const double *)C->pos[2], C->vel[0], C->vel[1], C->vel[2]);
+  HC_HIP(hipGetLastError());
+  return HC_OK;
+}
+
+// remove tagged cells (host round trip; rare)
+static int purge_tagged(hc_cells *C) {
+  HC_HIP(hipMemcpyAsync(C->h_ntag, C->d_ntag, sizeof(int), hipMemcpyDeviceToHost, hc::stream()));
+  HC_HIP(hipStreamSynchronize(hc::stream()));
+  if (*C->h_ntag == 0) return HC_OK;
+  long ncells = 0;
+  for (int t = 0; t < C->ntypes; t++) ncells += C->ncells[t];
+  std::vector<int> tags((size_t)ncells);
+  HC_HIP(hipMemcpy(tags.data(), C->d_tag, (size_t)ncells * sizeof(int), hipMemcpyDeviceToHost));
+  int rc = sync_to_host(C); if (rc != HC_OK) return rc;
+  long cell0 = 0;
+  for (int t = 0; t < C->ntypes; t++) {
+    const long nc = C->ncells[t]; const int nv = C->types[t]->host.nv;
+    std::vector<double> np, nvl, nf; std::vector<long> nid;
+    for (long c = 0; c < nc; c++) {
+      if (tags[(size_t)(cell0 + c)]) { C->n_deleted++; continue; }
+      np.insert(np.end(), C->hpos[t].begin() + 3 * c * nv, C->hpos[t].begin() + 3 * (c + 1) * nv);
+      nvl.insert(nvl.end(), C->hvel[t].begin() + 3 * c * nv, C->hvel[t].begin() + 3 * (c + 1) * nv);
+      nf.insert(nf.end(), C->hfrc[t].begin() + 3 * c * nv, C->hfrc[t].begin() + 3 * (c + 1) * nv);
+      nid.push_back(C->hids[t][(size_t)c]);
+    }
+    C->hpos[t].swap(np); C->hvel[t].swap(nvl); C->hfrc[t].swap(nf); C->hids[t].swap(nid);
+    cell0 += nc;
+  }
+  *C->h_ntag = 0;
+  HC_HIP(hipMemset(C->d_ntag, 0, sizeof(int)));
+  C->host_dirty = true;
+  return sync_to_device(C);
+}
+
+int hcp_advance(hc_cells *C, int check_deletions) {
+  HC_REQUIRE(C, "hcp_advance: null pointer");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  if (C->nverts == 0) return HC_OK;
+  {
+    hc::ProfScope prof(hc::PK_ADVANCE);
+    const LatView v = make_view(C->L);
+    hipLaunchKernelGGL(advance_kernel, dim3((unsigned)((C->nverts + 255) / 256)), dim3(256), 0, hc::stream(), v, C->nverts, C->pos[0], C->pos[1],
+                       C->pos[2], (const double *)C->vel[0], (const double *)C->vel[1], (const double *)C->vel[2], (const int *)C->d_vert_cell,
+                       C->d_tag, C->d_ntag);
+    HC_HIP(hipGetLastError());
+  }
+  if (check_deletions) return purge_tagged(C);
+  return HC_OK;
+}
+
+int hcp_mechanics(hc_cells *C, long iter, int forced) {
+  HC_REQUIRE(C, "hcp_mechanics: null pointer");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  hc::ProfScope prof(hc::PK_MECH);
+  for (int t = 0; t < C->ntypes; t++) {
+    if (!(iter % C->timescale[t] == 0 || forced)) continue;  // core/hemoCellParticleField.cpp:655
+    rc = launch_mechanics(C, t, nullptr);
+    if (rc != HC_OK) return rc;
+  }
+  return HC_OK;
+}
+
+int hcp_mechanics_components(hc_cells *C, int type, double *comp) {
+  HC_REQUIRE(C && comp && type >= 0 && type < C->ntypes, "hcp_mechanics_components: bad arguments");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  const long n = C->ncells[type] * C->types[type]->host.nv;
+  if (n == 0) return HC_OK;
+  double *d = nullptr;
+  HC_HIP(hipMalloc((void **)&d, (size_t)(18 * n) * sizeof(double)));
+  rc = launch_mechanics(C, type, d);
+  if (rc == HC_OK) {
+    hipError_t e = hipMemcpy(comp, d, (size_t)(18 * n) * sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = hc::hip_fail(e, "hipMemcpy", __FILE__, __LINE__);
+  }
+  hipFree(d);
+  return rc;
+}
+
+int hcp_cell_info(hc_cells *C, int type, double *volume, double *area, double *bbox, double *centroid) {
+  HC_REQUIRE(C && volume && area && bbox && centroid && type >= 0 && type < C->ntypes, "hcp_cell_info: bad arguments");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  const long nc = C->ncells[type];
+  if (nc == 0) return HC_OK;
+  const CellTables &T = C->types[type]->host;
+  double *d = nullptr;
+  HC_HIP(hipMalloc((void **)&d, (size_t)(11 * nc) * sizeof(double)));
+  const long f = C->first[type];
+  hipLaunchKernelGGL(cell_info_kernel, dim3((unsigned)nc), dim3(256), 0, hc::stream(), T.nv, T.nt, (const int *)C->types[type]->d_tri,
+                     (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f), d, d + nc, d + 2 * nc, d + 8 * nc);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(hc::stream());
+  if (e == hipSuccess) e = hipMemcpy(volume, d, nc * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(area, d + nc, nc * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(bbox, d + 2 * nc, 6 * nc * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(centroid, d + 8 * nc, 3 * nc * sizeof(double), hipMemcpyDeviceToHost);
+  hipFree(d);
+  if (e != hipSuccess) return hc::hip_fail(e, "hcp_cell_info", __FILE__, __LINE__);
+  return HC_OK;
+}
+
+int hc_iterate(hc_lattice *L, hc_cells *C, long *iter, int n, int particle_timescale, int force_limit, int deletion_check_every) {
+  HC_REQUIRE(L && C && iter, "hc_iterate: null pointer");
+  HC_REQUIRE(C->L == L, "hc_iterate: cells are bound to a different lattice");
+  HC_REQUIRE(L->n_slabs == 1, "hc_iterate: single-slab stepping only; multi-slab runs are driven phase by phase with halo exchange");
+  HC_REQUIRE(particle_timescale >= 1 && deletion_check_every >= 1, "hc_iterate: timescales must be >= 1");
+  int rc;
+  for (int s = 0; s < n; s++) {
+    const long it = *iter;
+    if ((rc = hcp_spread(C, force_limit)) != HC_OK) return rc;                  // core/hemoCell.cpp:313
+    if ((rc = hcl_collide_stream_part(L, 0)) != HC_OK) return rc;               // :317
+    hcl_step_end(L);
+    if (it % particle_timescale == 0) { if ((rc = hcp_interpolate(C)) != HC_OK) return rc; }   // :327-332
+    if ((rc = hcp_advance(C, (it % deletion_check_every) == 0)) != HC_OK) return rc;           // :342
+    if ((rc = hcp_mechanics(C, it, 0)) != HC_OK) return rc;                     // :345
+    *iter = it + 1;                                                             // :374 (force zeroing is fused into the collide kernel)
+  }
+  return HC_OK;
+}
+
+}  // extern "C"

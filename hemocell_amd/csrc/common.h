@@ -1,0 +1,64 @@
+// Internal declarations shared by the HIP translation units of libhemocell_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/hemocell_amd.h"
+
+namespace hc {
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+hipStream_t stream();
+
+#define HC_HIP(call)                                                         \
+  do {                                                                       \
+    hipError_t e__ = (call);                                                 \
+    if (e__ != hipSuccess) return hc::hip_fail(e__, #call, __FILE__, __LINE__); \
+  } while (0)
+
+#define HC_REQUIRE(cond, msg)                 \
+  do {                                        \
+    if (!(cond)) {                            \
+      hc::set_error(std::string(msg));        \
+      return HC_ERR_ARG;                      \
+    }                                         \
+  } while (0)
+
+// per-kernel hipEvent timing (hc_profile_*)
+enum ProfKernel { PK_COLLIDE = 0, PK_SPREAD, PK_INTERP, PK_ADVANCE, PK_MECH, PK_COUNT };
+struct ProfScope {
+  int k; bool on;
+  hipEvent_t a, b;
+  explicit ProfScope(int kernel);
+  ~ProfScope();
+};
+
+// D3Q19, Palabos ordering: opposite of i (1..9) is i+9.
+// (patch/palabos.patch:491-498)
+#define HC_CX {0, -1, 0, 0, -1, -1, -1, -1, 0, 0, 1, 0, 0, 1, 1, 1, 1, 0, 0}
+#define HC_CY {0, 0, -1, 0, -1, 1, 0, 0, -1, -1, 0, 1, 0, 1, -1, 0, 0, 1, 1}
+#define HC_CZ {0, 0, 0, -1, 0, 0, -1, 1, -1, 1, 0, 0, 1, 0, 0, 1, -1, 1, -1}
+
+constexpr int HALO = 2;  // x-halo planes on each side of a slab
+
+}  // namespace hc
+
+struct hc_lattice {
+  int nx, ny, nz;        // local bulk dims
+  int periodic[3];       // global periodicity
+  int x0, nx_global, n_slabs;
+  double omega;
+  size_t plane;          // ny*nz
+  size_t npad;           // (nx+2*HALO)*plane
+  double *f[2];          // [19][npad] post-collision populations (fBar), ping-pong
+  int cur;               // f[cur] is read by the next collide
+  double *force[2];      // [3][npad] IBM force accumulators, ping-pong
+  int fcur;              // force[fcur] is the one spread adds to / collide reads
+  uint8_t *mask;         // [npad]
+  std::vector<uint8_t> hmask;  // host copy (cell placement tests against it)
+  double body[3];
+  double *scratch;       // download staging
+  size_t scratch_doubles;
+};

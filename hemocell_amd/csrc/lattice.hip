@@ -1,0 +1,521 @@
+// D3Q19 Guo-forced BGK collide-stream for gfx950.
+//
+// Replaces Palabos MultiBlockLattice3D::collideAndStream() as called from
+// HemoCell::iterate (core/hemoCell.cpp:317) with GuoExternalForceBGKdynamics
+// (examples/pipeflow/pipeflow.cpp:71) and BounceBack walls (:73), plus the two
+// setExternalVector sweeps of core/hemoCell.cpp:369-371 and
+// examples/pipeflow/pipeflow.cpp:144-146 (fused: the body force is a kernel
+// argument, the per-node IBM force buffer of the *other* parity is zeroed here).
+//
+// Layout (HBM): structure of arrays f[q][x+HALO][y][z], z fastest, so that a
+// wavefront reads/writes 64 consecutive doubles of one population and an
+// x-plane of one population is contiguous (halo pack = plain copies).  Two
+// population buffers (A/B "pull" scheme): the stored state is the
+// POST-COLLISION field P_t; a step gathers S_t(x,i) = P_{t-1}(x - c_i, i)
+// (misaligned reads, aligned writes), collides and writes P_t.  The reference's
+// visible state after collideAndStream (post-stream S) is recovered by
+// hcl_download_populations with the same gather.
+//
+// Arithmetic follows oracle/hemo_oracle.c operation for operation (the library
+// is built with -ffp-contract=off) so that fluid-only runs are bit-identical.
+#include "common.h"
+
+using namespace hc;
+
+namespace {
+
+struct LatArgs {
+  const double *fin;
+  double *fout;
+  const double *Fin;   // IBM force to read   [3][npad]
+  double *Fzero;       // IBM force to zero   [3][npad]
+  const uint8_t *mask;
+  int nx, ny, nz;
+  int plane;
+  long npad;
+  int x_begin;
+  int wrap_x, per_y, per_z;
+  double omega;
+  double bx, by, bz;
+};
+
+struct Nbr {  // element offsets to the -1 / +1 neighbour along each axis, and validity
+  long xm, xp;
+  int ym, yp, zm, zp;
+  bool ym_ok, yp_ok, zm_ok, zp_ok;
+};
+
+__device__ __forceinline__ Nbr neighbours(const LatArgs &a, int x, int y, int z) {
+  Nbr n;
+  n.xm = -(long)a.plane; n.xp = (long)a.plane;
+  if (a.wrap_x) {
+    if (x == 0) n.xm = (long)(a.nx - 1) * a.plane;
+    if (x == a.nx - 1) n.xp = -(long)(a.nx - 1) * a.plane;
+  }
+  n.ym = -a.nz; n.yp = a.nz; n.ym_ok = n.yp_ok = true;
+  if (y == 0) { if (a.per_y) n.ym = (a.ny - 1) * a.nz; else n.ym_ok = false; }
+  if (y == a.ny - 1) { if (a.per_y) n.yp = -(a.ny - 1) * a.nz; else n.yp_ok = false; }
+  n.zm = -1; n.zp = 1; n.zm_ok = n.zp_ok = true;
+  if (z == 0) { if (a.per_z) n.zm = a.nz - 1; else n.zm_ok = false; }
+  if (z == a.nz - 1) { if (a.per_z) n.zp = -(a.nz - 1); else n.zp_ok = false; }
+  return n;
+}
+
+// offset from a node to (node - c_q)   [c = +1 -> the -1 neighbour]
+template <int CX, int CY, int CZ>
+__device__ __forceinline__ long src_off(const Nbr &n, bool &ok) {
+  long off = 0; ok = true;
+  if (CX == 1) off += n.xm; else if (CX == -1) off += n.xp;
+  if (CY == 1) { off += n.ym; ok = ok && n.ym_ok; } else if (CY == -1) { off += n.yp; ok = ok && n.yp_ok; }
+  if (CZ == 1) { off += n.zm; ok = ok && n.zm_ok; } else if (CZ == -1) { off += n.zp; ok = ok && n.zp_ok; }
+  return off;
+}
+// offset from a node to (node + c_q)
+template <int CX, int CY, int CZ>
+__device__ __forceinline__ long dst_off(const Nbr &n, bool &ok) {
+  long off = 0; ok = true;
+  if (CX == 1) off += n.xp; else if (CX == -1) off += n.xm;
+  if (CY == 1) { off += n.yp; ok = ok && n.yp_ok; } else if (CY == -1) { off += n.ym; ok = ok && n.ym_ok; }
+  if (CZ == 1) { off += n.zp; ok = ok && n.zp_ok; } else if (CZ == -1) { off += n.zm; ok = ok && n.zm_ok; }
+  return off;
+}
+
+#define FOR_Q(M)                                                                                     \
+  M(0, 0, 0, 0) M(1, -1, 0, 0) M(2, 0, -1, 0) M(3, 0, 0, -1) M(4, -1, -1, 0) M(5, -1, 1, 0)          \
+  M(6, -1, 0, -1) M(7, -1, 0, 1) M(8, 0, -1, -1) M(9, 0, -1, 1) M(10, 1, 0, 0) M(11, 0, 1, 0)        \
+  M(12, 0, 0, 1) M(13, 1, 1, 0) M(14, 1, -1, 0) M(15, 1, 0, 1) M(16, 1, 0, -1) M(17, 0, 1, 1)        \
+  M(18, 0, 1, -1)
+
+__device__ __forceinline__ constexpr double tq(int q) { return q == 0 ? 1. / 3. : ((q >= 1 && q <= 3) || (q >= 10 && q <= 12)) ? 1. / 18. : 1. / 36.; }
+
+// gather the post-stream populations S(node, q) = P(node - c_q, q)
+__device__ __forceinline__ void pull(const double *__restrict__ fin, long npad, long node, const Nbr &n, double f[HC_Q]) {
+#define M(Q, CX, CY, CZ)                                   \
+  {                                                        \
+    bool ok; long off = src_off<CX, CY, CZ>(n, ok);        \
+    f[Q] = ok ? fin[(long)Q * npad + node + off] : 0.0;    \
+  }
+  FOR_Q(M)
+#undef M
+}
+
+// moments in the oracle's order: ascending q, zero-velocity components skipped
+__device__ __forceinline__ void moments(const double f[HC_Q], double &rhoBar, double &jx, double &jy, double &jz) {
+  double r = 0.0, x = 0.0, y = 0.0, z = 0.0;
+#define M(Q, CX, CY, CZ)              \
+  r += f[Q];                          \
+  if (CX == 1) x += f[Q]; else if (CX == -1) x += -f[Q]; \
+  if (CY == 1) y += f[Q]; else if (CY == -1) y += -f[Q]; \
+  if (CZ == 1) z += f[Q]; else if (CZ == -1) z += -f[Q];
+  FOR_Q(M)
+#undef M
+  rhoBar = r; jx = x; jy = y; jz = z;
+}
+
+template <int CX, int CY, int CZ>
+__device__ __forceinline__ double cdot(double a0, double a1, double a2) {
+  // ((cx*a0 + cy*a1) + cz*a2) with the zero terms dropped (exact)
+  double s = 0.0; bool first = true;
+  if (CX != 0) { s = (CX == 1 ? a0 : -a0); first = false; }
+  if (CY != 0) { double t = (CY == 1 ? a1 : -a1); s = first ? t : s + t; first = false; }
+  if (CZ != 0) { double t = (CZ == 1 ? a2 : -a2); s = first ? t : s + t; first = false; }
+  return s;
+}
+
+// GuoExternalForceBGKdynamics::collide, operation order of oracle/hemo_oracle.c collide_guo_bgk
+__device__ __forceinline__ void collide_guo(double f[HC_Q], double Fx, double Fy, double Fz, double omega) {
+  double rhoBar, j0, j1, j2;
+  moments(f, rhoBar, j0, j1, j2);
+  const double invRho = 1.0 / (1.0 + rhoBar);
+  const double rho = 1.0 + rhoBar;
+  const double u0 = j0 * invRho + Fx / 2.0, u1 = j1 * invRho + Fy / 2.0, u2 = j2 * invRho + Fz / 2.0;
+  j0 = rho * u0; j1 = rho * u1; j2 = rho * u2;
+  const double jSqr = j0 * j0 + j1 * j1 + j2 * j2;
+  const double one_m_omega = 1.0 - omega;
+  const double guo = 1.0 - omega / 2.0;
+#define M(Q, CX, CY, CZ)                                                                     \
+  {                                                                                          \
+    const double c_j = cdot<CX, CY, CZ>(j0, j1, j2);                                         \
+    const double feq = tq(Q) * (rhoBar + 3.0 * c_j + invRho * (4.5 * c_j * c_j - 1.5 * jSqr)); \
+    f[Q] *= one_m_omega;                                                                     \
+    f[Q] += omega * feq;                                                                     \
+  }
+  FOR_Q(M)
+#undef M
+#define M(Q, CX, CY, CZ)                                                                     \
+  {                                                                                          \
+    double c_u = cdot<CX, CY, CZ>(u0, u1, u2);                                               \
+    c_u *= 9.0;                                                                              \
+    double ft = (((double)CX - u0) * 3.0 + c_u * (double)CX) * Fx;                           \
+    ft += (((double)CY - u1) * 3.0 + c_u * (double)CY) * Fy;                                 \
+    ft += (((double)CZ - u2) * 3.0 + c_u * (double)CZ) * Fz;                                 \
+    ft *= tq(Q);                                                                             \
+    ft *= guo;                                                                               \
+    f[Q] += ft;                                                                              \
+  }
+  FOR_Q(M)
+#undef M
+}
+
+__global__ __launch_bounds__(256) void collide_stream_kernel(LatArgs a) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.plane) return;
+  const int x = a.x_begin + blockIdx.y;
+  const int y = p / a.nz, z = p - y * a.nz;
+  const long node = (long)(x + HALO) * a.plane + p;
+  const Nbr n = neighbours(a, x, y, z);
+  double f[HC_Q];
+  pull(a.fin, a.npad, node, n, f);
+  const bool wall = a.mask[node] != 0;
+  if (wall) {
+    // BounceBack::collide: swap opposite pairs (full-way bounce-back)
+#pragma unroll
+    for (int i = 1; i <= 9; i++) { double t = f[i]; f[i] = f[i + 9]; f[i + 9] = t; }
+  } else {
+    const double Fx = a.bx + a.Fin[node], Fy = a.by + a.Fin[a.npad + node], Fz = a.bz + a.Fin[2 * a.npad + node];
+    collide_guo(f, Fx, Fy, Fz, a.omega);
+  }
+#pragma unroll
+  for (int q = 0; q < HC_Q; q++) a.fout[(long)q * a.npad + node] = f[q];
+  a.Fzero[node] = 0.0; a.Fzero[a.npad + node] = 0.0; a.Fzero[2 * a.npad + node] = 0.0;
+}
+
+// P(y,i) = mask[y+c_i] ? 0 : feq_i(rho,u): initializeAtEquilibrium in the shifted representation
+__global__ void init_eq_kernel(LatArgs a, double rhoBar, double j0, double j1, double j2) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.plane) return;
+  const int x = a.x_begin + blockIdx.y;
+  const int y = p / a.nz, z = p - y * a.nz;
+  const long node = (long)(x + HALO) * a.plane + p;
+  const Nbr n = neighbours(a, x, y, z);
+  const double invRho = 1.0 / (1.0 + rhoBar);
+  const double jSqr = j0 * j0 + j1 * j1 + j2 * j2;
+#define M(Q, CX, CY, CZ)                                                                        \
+  {                                                                                             \
+    bool ok; long off = dst_off<CX, CY, CZ>(n, ok);                                             \
+    double v = 0.0;                                                                             \
+    if (ok && a.mask[node + off] == 0) {                                                        \
+      const double c_j = cdot<CX, CY, CZ>(j0, j1, j2);                                          \
+      v = tq(Q) * (rhoBar + 3.0 * c_j + invRho * (4.5 * c_j * c_j - 1.5 * jSqr));               \
+    }                                                                                           \
+    a.fout[(long)Q * a.npad + node] = v;                                                        \
+  }
+  FOR_Q(M)
+#undef M
+}
+
+// AoS [node][19] of the post-stream state, bulk nodes only
+__global__ void download_kernel(LatArgs a, double *aos) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.plane) return;
+  const int x = a.x_begin + blockIdx.y;
+  const int y = p / a.nz, z = p - y * a.nz;
+  const long node = (long)(x + HALO) * a.plane + p;
+  const Nbr n = neighbours(a, x, y, z);
+  double f[HC_Q];
+  pull(a.fin, a.npad, node, n, f);
+  const long o = ((long)x * a.plane + p) * HC_Q;
+#pragma unroll
+  for (int q = 0; q < HC_Q; q++) aos[o + q] = f[q];
+}
+
+// inverse of download: P(y,i) = S(y+c_i, i) (0 if the target lies outside)
+__global__ void upload_kernel(LatArgs a, const double *aos) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.plane) return;
+  const int x = a.x_begin + blockIdx.y;
+  const int y = p / a.nz, z = p - y * a.nz;
+  const long node = (long)(x + HALO) * a.plane + p;
+  const long bulk = (long)x * a.plane + p;
+  const Nbr n = neighbours(a, x, y, z);
+#define M(Q, CX, CY, CZ)                                                                  \
+  {                                                                                       \
+    bool ok; long off = dst_off<CX, CY, CZ>(n, ok);                                       \
+    /* without x wrap the +-x neighbour of a face plane is a halo plane: outside */       \
+    if (!a.wrap_x && ((CX == 1 && x == a.nx - 1) || (CX == -1 && x == 0))) ok = false;    \
+    a.fout[(long)Q * a.npad + node] = ok ? aos[(bulk + off) * HC_Q + Q] : 0.0;            \
+  }
+  FOR_Q(M)
+#undef M
+}
+
+__global__ void rho_u_kernel(LatArgs a, double *rho, double *u) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.plane) return;
+  const int x = a.x_begin + blockIdx.y;
+  const int y = p / a.nz, z = p - y * a.nz;
+  const long node = (long)(x + HALO) * a.plane + p;
+  const Nbr n = neighbours(a, x, y, z);
+  double f[HC_Q];
+  pull(a.fin, a.npad, node, n, f);
+  double rhoBar, j0, j1, j2;
+  moments(f, rhoBar, j0, j1, j2);
+  const double invRho = 1.0 / (1.0 + rhoBar);
+  const long o = (long)x * a.plane + p;
+  rho[o] = 1.0 + rhoBar;
+  u[3 * o] = j0 * invRho + (a.bx + a.Fin[node]) / 2.0;
+  u[3 * o + 1] = j1 * invRho + (a.by + a.Fin[a.npad + node]) / 2.0;
+  u[3 * o + 2] = j2 * invRho + (a.bz + a.Fin[2 * a.npad + node]) / 2.0;
+}
+
+__global__ void force_aos_kernel(LatArgs a, double *F) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.plane) return;
+  const int x = a.x_begin + blockIdx.y;
+  const long node = (long)(x + HALO) * a.plane + p;
+  const long o = (long)x * a.plane + p;
+  for (int d = 0; d < 3; d++) F[3 * o + d] = a.Fin[d * a.npad + node];
+}
+
+struct HaloArgs {
+  double *f;          // population buffer
+  double *buf;        // contiguous staging
+  long npad; int plane;
+  int npops; int pops[HC_Q];
+  int width; int x_first;   // padded x index of the first plane
+  int to_buf;
+};
+__global__ void halo_copy_kernel(HaloArgs h) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= h.plane) return;
+  const int w = blockIdx.y % h.width, k = blockIdx.y / h.width;
+  const long li = (long)h.pops[k] * h.npad + (long)(h.x_first + w) * h.plane + p;
+  const long bi = ((long)k * h.width + w) * h.plane + p;
+  if (h.to_buf) h.buf[bi] = h.f[li]; else h.f[li] = h.buf[bi];
+}
+
+LatArgs make_args(const hc_lattice *L) {
+  LatArgs a;
+  a.fin = L->f[L->cur]; a.fout = L->f[1 - L->cur];
+  a.Fin = L->force[L->fcur]; a.Fzero = L->force[1 - L->fcur];
+  a.mask = L->mask;
+  a.nx = L->nx; a.ny = L->ny; a.nz = L->nz; a.plane = (int)L->plane; a.npad = (long)L->npad;
+  a.x_begin = 0;
+  a.wrap_x = (L->n_slabs == 1 && L->periodic[0]) ? 1 : 0;
+  a.per_y = L->periodic[1]; a.per_z = L->periodic[2];
+  a.omega = L->omega; a.bx = L->body[0]; a.by = L->body[1]; a.bz = L->body[2];
+  return a;
+}
+
+dim3 plane_grid(const hc_lattice *L, int nplanes) { return dim3((unsigned)((L->plane + 255) / 256), (unsigned)nplanes, 1); }
+
+int ensure_scratch(hc_lattice *L, size_t doubles) {
+  if (L->scratch_doubles >= doubles) return HC_OK;
+  if (L->scratch) HC_HIP(hipFree(L->scratch));
+  L->scratch = nullptr; L->scratch_doubles = 0;
+  HC_HIP(hipMalloc((void **)&L->scratch, doubles * sizeof(double)));
+  L->scratch_doubles = doubles;
+  return HC_OK;
+}
+
+int launch_collide(hc_lattice *L, int x_begin, int nplanes) {
+  if (nplanes <= 0) return HC_OK;
+  LatArgs a = make_args(L);
+  a.x_begin = x_begin;
+  hipLaunchKernelGGL(collide_stream_kernel, plane_grid(L, nplanes), dim3(256), 0, hc::stream(), a);
+  HC_HIP(hipGetLastError());
+  return HC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hcl_create(hc_lattice **out, int nx, int ny, int nz, const int periodic[3], double omega,
+               int x0, int nx_global, int n_slabs) {
+  HC_REQUIRE(out && periodic, "hcl_create: null pointer");
+  HC_REQUIRE(nx >= 2 && ny >= 2 && nz >= 2, "hcl_create: every dimension must be >= 2");
+  HC_REQUIRE(n_slabs >= 1 && nx_global >= nx && x0 >= 0 && x0 + nx <= nx_global, "hcl_create: inconsistent slab decomposition");
+  HC_REQUIRE((long)ny * nz < (1L << 30) && (long)(nx + 2 * HALO) * ny * nz < (1L << 31), "hcl_create: slab too large for 32-bit plane indexing");
+  HC_REQUIRE(omega > 0.0 && omega < 2.0, "hcl_create: omega must be in (0,2)");
+  if (hc::stream() == nullptr) { hc::set_error("hcl_create: hc_init() has not been called"); return HC_ERR_STATE; }
+  hc_lattice *L = new hc_lattice();
+  L->nx = nx; L->ny = ny; L->nz = nz;
+  for (int d = 0; d < 3; d++) L->periodic[d] = periodic[d] ? 1 : 0;
+  L->x0 = x0; L->nx_global = nx_global; L->n_slabs = n_slabs;
+  L->omega = omega;
+  L->plane = (size_t)ny * nz;
+  L->npad = (size_t)(nx + 2 * HALO) * L->plane;
+  L->cur = 0; L->fcur = 0;
+  L->body[0] = L->body[1] = L->body[2] = 0.0;
+  L->scratch = nullptr; L->scratch_doubles = 0;
+  L->f[0] = L->f[1] = L->force[0] = L->force[1] = nullptr; L->mask = nullptr;
+  for (int k = 0; k < 2; k++) {
+    HC_HIP(hipMalloc((void **)&L->f[k], L->npad * HC_Q * sizeof(double)));
+    HC_HIP(hipMemsetAsync(L->f[k], 0, L->npad * HC_Q * sizeof(double), hc::stream()));
+    HC_HIP(hipMalloc((void **)&L->force[k], L->npad * 3 * sizeof(double)));
+    HC_HIP(hipMemsetAsync(L->force[k], 0, L->npad * 3 * sizeof(double), hc::stream()));
+  }
+  HC_HIP(hipMalloc((void **)&L->mask, L->npad));
+  HC_HIP(hipMemsetAsync(L->mask, 0, L->npad, hc::stream()));
+  L->hmask.assign(L->npad, 0);
+  HC_HIP(hipStreamSynchronize(hc::stream()));
+  *out = L;
+  return HC_OK;
+}
+
+int hcl_destroy(hc_lattice *L) {
+  if (!L) return HC_OK;
+  hipStreamSynchronize(hc::stream());
+  for (int k = 0; k < 2; k++) { if (L->f[k]) hipFree(L->f[k]); if (L->force[k]) hipFree(L->force[k]); }
+  if (L->mask) hipFree(L->mask);
+  if (L->scratch) hipFree(L->scratch);
+  delete L;
+  return HC_OK;
+}
+
+int hcl_dims(const hc_lattice *L, int dims[3]) {
+  HC_REQUIRE(L && dims, "hcl_dims: null pointer");
+  dims[0] = L->nx; dims[1] = L->ny; dims[2] = L->nz;
+  return HC_OK;
+}
+
+int hcl_set_mask(hc_lattice *L, const uint8_t *mask_with_halo) {
+  HC_REQUIRE(L && mask_with_halo, "hcl_set_mask: null pointer");
+  L->hmask.assign(mask_with_halo, mask_with_halo + L->npad);
+  HC_HIP(hipMemcpyAsync(L->mask, mask_with_halo, L->npad, hipMemcpyHostToDevice, hc::stream()));
+  HC_HIP(hipStreamSynchronize(hc::stream()));
+  return HC_OK;
+}
+
+int hcl_init_equilibrium(hc_lattice *L, double rho, const double u[3]) {
+  HC_REQUIRE(L && u, "hcl_init_equilibrium: null pointer");
+  LatArgs a = make_args(L);
+  a.fout = L->f[L->cur];
+  HC_HIP(hipMemsetAsync(L->f[0], 0, L->npad * HC_Q * sizeof(double), hc::stream()));
+  HC_HIP(hipMemsetAsync(L->f[1], 0, L->npad * HC_Q * sizeof(double), hc::stream()));
+  hipLaunchKernelGGL(init_eq_kernel, plane_grid(L, L->nx), dim3(256), 0, hc::stream(), a, rho - 1.0, rho * u[0], rho * u[1], rho * u[2]);
+  HC_HIP(hipGetLastError());
+  HC_HIP(hipStreamSynchronize(hc::stream()));
+  return HC_OK;
+}
+
+int hcl_set_body_force(hc_lattice *L, const double F[3]) {
+  HC_REQUIRE(L && F, "hcl_set_body_force: null pointer");
+  for (int d = 0; d < 3; d++) L->body[d] = F[d];
+  return HC_OK;
+}
+
+int hcl_collide_stream_part(hc_lattice *L, int part) {
+  HC_REQUIRE(L, "hcl_collide_stream_part: null lattice");
+  HC_REQUIRE(part >= 0 && part <= 2, "hcl_collide_stream_part: part must be 0, 1 or 2");
+  hc::ProfScope prof(hc::PK_COLLIDE);
+  int rc = HC_OK;
+  if (part == 0) rc = launch_collide(L, 0, L->nx);
+  else if (part == 1) rc = launch_collide(L, 1, L->nx - 2);
+  else { rc = launch_collide(L, 0, 1); if (rc == HC_OK) rc = launch_collide(L, L->nx - 1, 1); }
+  return rc;
+}
+
+int hcl_step_end(hc_lattice *L) {
+  HC_REQUIRE(L, "hcl_step_end: null lattice");
+  L->cur ^= 1; L->fcur ^= 1;
+  return HC_OK;
+}
+
+int hcl_collide_stream(hc_lattice *L, int nsteps) {
+  HC_REQUIRE(L, "hcl_collide_stream: null lattice");
+  HC_REQUIRE(L->n_slabs == 1, "hcl_collide_stream: multi-slab lattices are stepped with hcl_collide_stream_part + halo exchange");
+  for (int s = 0; s < nsteps; s++) {
+    int rc = hcl_collide_stream_part(L, 0);
+    if (rc != HC_OK) return rc;
+    hcl_step_end(L);
+  }
+  return HC_OK;
+}
+
+int hcl_download_populations(hc_lattice *L, double *f_aos) {
+  HC_REQUIRE(L && f_aos, "hcl_download_populations: null pointer");
+  const size_t nd = (size_t)L->nx * L->plane * HC_Q;
+  int rc = ensure_scratch(L, nd); if (rc != HC_OK) return rc;
+  LatArgs a = make_args(L);
+  hipLaunchKernelGGL(download_kernel, plane_grid(L, L->nx), dim3(256), 0, hc::stream(), a, L->scratch);
+  HC_HIP(hipGetLastError());
+  HC_HIP(hipMemcpyAsync(f_aos, L->scratch, nd * sizeof(double), hipMemcpyDeviceToHost, hc::stream()));
+  HC_HIP(hipStreamSynchronize(hc::stream()));
+  return HC_OK;
+}
+
+int hcl_upload_populations(hc_lattice *L, const double *f_aos) {
+  HC_REQUIRE(L && f_aos, "hcl_upload_populations: null pointer");
+  const size_t nd = (size_t)L->nx * L->plane * HC_Q;
+  int rc = ensure_scratch(L, nd); if (rc != HC_OK) return rc;
+  HC_HIP(hipMemcpyAsync(L->scratch, f_aos, nd * sizeof(double), hipMemcpyHostToDevice, hc::stream()));
+  LatArgs a = make_args(L);
+  a.fout = L->f[L->cur];
+  hipLaunchKernelGGL(upload_kernel, plane_grid(L, L->nx), dim3(256), 0, hc::stream(), a, (const double *)L->scratch);
+  HC_HIP(hipGetLastError());
+  HC_HIP(hipStreamSynchronize(hc::stream()));
+  return HC_OK;
+}
+
+int hcl_download_rho_u(hc_lattice *L, double *rho, double *u) {
+  HC_REQUIRE(L && rho && u, "hcl_download_rho_u: null pointer");
+  const size_t n = (size_t)L->nx * L->plane;
+  int rc = ensure_scratch(L, n * 4); if (rc != HC_OK) return rc;
+  LatArgs a = make_args(L);
+  hipLaunchKernelGGL(rho_u_kernel, plane_grid(L, L->nx), dim3(256), 0, hc::stream(), a, L->scratch, L->scratch + n);
+  HC_HIP(hipGetLastError());
+  HC_HIP(hipMemcpyAsync(rho, L->scratch, n * sizeof(double), hipMemcpyDeviceToHost, hc::stream()));
+  HC_HIP(hipMemcpyAsync(u, L->scratch + n, 3 * n * sizeof(double), hipMemcpyDeviceToHost, hc::stream()));
+  HC_HIP(hipStreamSynchronize(hc::stream()));
+  return HC_OK;
+}
+
+int hcl_download_ibm_force(hc_lattice *L, double *F) {
+  HC_REQUIRE(L && F, "hcl_download_ibm_force: null pointer");
+  const size_t n = (size_t)L->nx * L->plane;
+  int rc = ensure_scratch(L, n * 3); if (rc != HC_OK) return rc;
+  LatArgs a = make_args(L);
+  hipLaunchKernelGGL(force_aos_kernel, plane_grid(L, L->nx), dim3(256), 0, hc::stream(), a, L->scratch);
+  HC_HIP(hipGetLastError());
+  HC_HIP(hipMemcpyAsync(F, L->scratch, 3 * n * sizeof(double), hipMemcpyDeviceToHost, hc::stream()));
+  HC_HIP(hipStreamSynchronize(hc::stream()));
+  return HC_OK;
+}
+
+int hcl_zero_ibm_force(hc_lattice *L) {
+  HC_REQUIRE(L, "hcl_zero_ibm_force: null lattice");
+  HC_HIP(hipMemsetAsync(L->force[L->fcur], 0, L->npad * 3 * sizeof(double), hc::stream()));
+  return HC_OK;
+}
+
+size_t hcl_halo_doubles(const hc_lattice *L, int width) {
+  if (!L) return 0;
+  return (size_t)(width == 1 ? 5 : HC_Q) * (size_t)width * L->plane;
+}
+
+static int halo_copy(hc_lattice *L, int side, int width, double *buf, int to_buf) {
+  HC_REQUIRE(L && buf, "hcl_halo: null pointer");
+  HC_REQUIRE((side == 0 || side == 1) && (width == 1 || width == 2), "hcl_halo: side must be 0/1 and width 1/2");
+  HC_REQUIRE(L->nx >= 2 * width, "hcl_halo: slab thinner than the halo");
+  static const int cxm[5] = {1, 4, 5, 6, 7};        // c_x = -1
+  static const int cxp[5] = {10, 13, 14, 15, 16};   // c_x = +1
+  HaloArgs h;
+  h.f = L->f[L->cur]; h.buf = buf; h.npad = (long)L->npad; h.plane = (int)L->plane; h.width = width; h.to_buf = to_buf;
+  if (width == 2) { h.npops = HC_Q; for (int q = 0; q < HC_Q; q++) h.pops[q] = q; }
+  else {
+    h.npops = 5;
+    // pack low face: the low neighbour pulls c_x=-1 populations from x+1 -> send c_x=-1 of plane 0
+    // pack high face: send c_x=+1 of plane nx-1
+    // unpack low halo (plane -1): receives the low neighbour's high face -> c_x=+1
+    // unpack high halo (plane nx): receives c_x=-1
+    const int *src = to_buf ? (side == 0 ? cxm : cxp) : (side == 0 ? cxp : cxm);
+    for (int k = 0; k < 5; k++) h.pops[k] = src[k];
+  }
+  if (to_buf) h.x_first = (side == 0) ? HALO : HALO + L->nx - width;
+  else h.x_first = (side == 0) ? HALO - width : HALO + L->nx;
+  hipLaunchKernelGGL(halo_copy_kernel, dim3((unsigned)((L->plane + 255) / 256), (unsigned)(h.npops * width), 1), dim3(256), 0, hc::stream(), h);
+  HC_HIP(hipGetLastError());
+  return HC_OK;
+}
+int hcl_halo_pack(hc_lattice *L, int side, int width, double *dev_buf) { return halo_copy(L, side, width, dev_buf, 1); }
+int hcl_halo_unpack(hc_lattice *L, int side, int width, const double *dev_buf) { return halo_copy(L, side, width, (double *)dev_buf, 0); }
+
+double hcl_mlups_bytes_per_node(const hc_lattice *L) {
+  (void)L;
+  // 19 reads + 19 writes of fp64 populations, 3 reads of the IBM force, 3 zeroing writes, 1 mask byte
+  return 19 * 8 * 2 + 3 * 8 * 2 + 1;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// Runtime plumbing of libhemocell_amd.so: error string, device selection,
+// stream, per-kernel hipEvent profiling.
+#include "common.h"
+#include <cstring>
+#include <mutex>
+
+namespace hc {
+
+static thread_local std::string g_error;
+static hipStream_t g_own_stream = nullptr;
+static hipStream_t g_stream = nullptr;
+static bool g_initialised = false;
+static bool g_profile = false;
+
+struct ProfRecord { hipEvent_t a, b; };
+static std::vector<ProfRecord> g_prof[PK_COUNT];
+static double g_prof_ms[PK_COUNT];
+static long g_prof_n[PK_COUNT];
+
+void set_error(const std::string &msg) { g_error = msg; }
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+  g_error = std::string("HIP error ") + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ") in " + what + " at " + file + ":" + std::to_string(line);
+  return HC_ERR_HIP;
+}
+hipStream_t stream() { return g_stream; }
+
+ProfScope::ProfScope(int kernel) : k(kernel), on(g_profile), a(nullptr), b(nullptr) {
+  if (!on) return;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+  hipEventRecord(a, g_stream);
+}
+ProfScope::~ProfScope() {
+  if (!on) return;
+  hipEventRecord(b, g_stream);
+  g_prof[k].push_back({a, b});
+}
+
+static void prof_collect() {
+  for (int k = 0; k < PK_COUNT; k++) {
+    for (auto &r : g_prof[k]) {
+      hipEventSynchronize(r.b);
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { g_prof_ms[k] += ms; g_prof_n[k]++; }
+      hipEventDestroy(r.a); hipEventDestroy(r.b);
+    }
+    g_prof[k].clear();
+  }
+}
+
+}  // namespace hc
+
+extern "C" {
+
+const char *hc_last_error(void) { return hc::g_error.c_str(); }
+
+int hc_device_count(int *count) {
+  HC_REQUIRE(count, "hc_device_count: null pointer");
+  HC_HIP(hipGetDeviceCount(count));
+  return HC_OK;
+}
+
+int hc_init(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) {
+    hc::set_error("hc_init: no HIP device available -- libhemocell_amd has no CPU fallback");
+    return HC_ERR_HIP;
+  }
+  HC_REQUIRE(device >= 0 && device < n, "hc_init: device index out of range");
+  HC_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HC_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    hc::set_error(std::string("hc_init: device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only");
+    return HC_ERR_HIP;
+  }
+  if (!hc::g_own_stream) HC_HIP(hipStreamCreateWithFlags(&hc::g_own_stream, hipStreamNonBlocking));
+  if (!hc::g_stream) hc::g_stream = hc::g_own_stream;
+  hc::g_initialised = true;
+  return HC_OK;
+}
+
+int hc_set_stream(void *hip_stream) {
+  hc::g_stream = hip_stream ? (hipStream_t)hip_stream : hc::g_own_stream;
+  return HC_OK;
+}
+
+int hc_synchronize(void) {
+  HC_HIP(hipStreamSynchronize(hc::g_stream));
+  return HC_OK;
+}
+
+int hc_profile_enable(int on) { hc::g_profile = on != 0; return HC_OK; }
+int hc_profile_reset(void) {
+  hc::prof_collect();
+  for (int k = 0; k < hc::PK_COUNT; k++) { hc::g_prof_ms[k] = 0; hc::g_prof_n[k] = 0; }
+  return HC_OK;
+}
+int hc_profile_read(const char *kernel, double *total_ms, long *launches) {
+  HC_REQUIRE(kernel && total_ms && launches, "hc_profile_read: null pointer");
+  static const char *names[hc::PK_COUNT] = {"collide_stream", "ibm_spread", "ibm_interpolate", "advance", "mechanics"};
+  hc::prof_collect();
+  for (int k = 0; k < hc::PK_COUNT; k++)
+    if (std::strcmp(kernel, names[k]) == 0) { *total_ms = hc::g_prof_ms[k]; *launches = hc::g_prof_n[k]; return HC_OK; }
+  hc::set_error(std::string("hc_profile_read: unknown kernel ") + kernel);
+  return HC_ERR_ARG;
+}
+
+}  // extern "C"

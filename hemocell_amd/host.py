@@ -1,0 +1,329 @@
+"""Thin numpy-facing host layer over the C ABI.
+
+Names follow the reference's interface for this path (hemocell.h:86-253,
+core/hemoCellFields.h:103-158): latticeEquilibrium, collideAndStream,
+spreadParticleForce, interpolateFluidVelocity, advanceParticles,
+applyConstitutiveModel, iterate, setMaterialTimeScaleSeparation ...  Every
+method is one call into libhemocell_amd.so; nothing is computed here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import Material, Params, check, dptr, lptr
+
+HALO = 2
+
+MODEL_RBC_HO = 0
+MODEL_PLT_SIMPLE = 1
+RBC_FROM_SPHERE = 1        # config/constant_defaults.h:80
+ELLIPSOID_FROM_SPHERE = 6  # config/constant_defaults.h:81
+
+# examples/pipeflow/PLT.xml:14-38
+PLT_INNER_EDGES = np.array([[60, 65], [62, 64], [37, 42], [54, 56], [34, 40], [25, 46], [50, 59], [29, 47],
+                            [61, 63], [26, 45], [33, 43], [27, 35], [32, 39], [49, 51], [0, 4], [48, 52],
+                            [6, 10], [53, 55], [19, 21], [57, 58], [15, 13]], dtype=np.int64)
+
+_initialised = False
+
+
+def init(device=0):
+    """plb::plbInit equivalent: select the GPU; raises if no gfx950 device."""
+    global _initialised
+    check(capi.lib().hc_init(device))
+    _initialised = True
+
+
+def ensure_init():
+    if not _initialised:
+        init(0)
+
+
+def base_parameters(dx=5e-7, dt=1e-7, nuP=1.1e-6, rhoP=1025.0, kBT=4.100531391e-21):
+    """param::lbm_base_parameters(cfg) (mechanics/constantConversion.cpp:36-59)"""
+    P = Params()
+    check(capi.lib().hc_params_base(C.byref(P), dx, dt, nuP, rhoP, kBT))
+    return P
+
+
+class Lattice:
+    """One x-slab of the MultiBlockLattice3D<T,DESCRIPTOR> with GuoExternalForceBGKdynamics."""
+
+    def __init__(self, nx, ny, nz, periodic=(False, False, False), omega=1.0, x0=0, nx_global=None, n_slabs=1):
+        ensure_init()
+        self.lib = capi.lib()
+        self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
+        self.x0 = int(x0)
+        self.nx_global = int(nx_global if nx_global is not None else nx)
+        self.n_slabs = int(n_slabs)
+        self.periodic = tuple(bool(p) for p in periodic)
+        per = (C.c_int * 3)(*[int(p) for p in periodic])
+        self.ptr = C.c_void_p()
+        check(self.lib.hcl_create(C.byref(self.ptr), self.nx, self.ny, self.nz, per, float(omega),
+                                  self.x0, self.nx_global, self.n_slabs))
+        self.n = self.nx * self.ny * self.nz
+
+    # defineDynamics(lattice, flagMatrix, bbox, new BounceBack(1.), 0)
+    def defineBounceBack(self, mask_global):
+        """mask_global: uint8 [nx_global][ny][nz] (1 = BounceBack).  The slab's halo planes are filled
+        from the global array (periodic wrap in x if enabled, otherwise wall)."""
+        m = np.ascontiguousarray(mask_global, dtype=np.uint8)
+        assert m.shape == (self.nx_global, self.ny, self.nz), m.shape
+        xs = np.arange(self.x0 - HALO, self.x0 + self.nx + HALO)
+        if self.periodic[0]:
+            local = m[np.mod(xs, self.nx_global)]
+        else:
+            local = np.ones((len(xs), self.ny, self.nz), np.uint8)
+            ok = (xs >= 0) & (xs < self.nx_global)
+            local[ok] = m[xs[ok]]
+        local = np.ascontiguousarray(local)
+        check(self.lib.hcl_set_mask(self.ptr, local.ctypes.data))
+
+    def latticeEquilibrium(self, rho=1.0, u=(0.0, 0.0, 0.0)):
+        uu = np.array(u, dtype=np.float64)
+        check(self.lib.hcl_init_equilibrium(self.ptr, float(rho), dptr(uu)))
+
+    def setExternalVector(self, F):
+        ff = np.array(F, dtype=np.float64)
+        check(self.lib.hcl_set_body_force(self.ptr, dptr(ff)))
+
+    def collideAndStream(self, steps=1):
+        check(self.lib.hcl_collide_stream(self.ptr, int(steps)))
+
+    def collide_part(self, part):
+        check(self.lib.hcl_collide_stream_part(self.ptr, int(part)))
+
+    def step_end(self):
+        check(self.lib.hcl_step_end(self.ptr))
+
+    def populations(self):
+        """[n][19] post-stream populations (f - t_i), reference node order z + nz*(y + ny*x)"""
+        out = np.empty((self.n, 19), dtype=np.float64)
+        check(self.lib.hcl_download_populations(self.ptr, dptr(out)))
+        return out
+
+    def set_populations(self, f):
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        assert f.shape == (self.n, 19)
+        check(self.lib.hcl_upload_populations(self.ptr, dptr(f)))
+
+    def rho_u(self):
+        rho = np.empty(self.n, dtype=np.float64)
+        u = np.empty((self.n, 3), dtype=np.float64)
+        check(self.lib.hcl_download_rho_u(self.ptr, dptr(rho), dptr(u)))
+        return rho, u
+
+    def ibm_force(self):
+        F = np.empty((self.n, 3), dtype=np.float64)
+        check(self.lib.hcl_download_ibm_force(self.ptr, dptr(F)))
+        return F
+
+    def halo_doubles(self, width):
+        return int(self.lib.hcl_halo_doubles(self.ptr, int(width)))
+
+    def halo_pack(self, side, width, dev_ptr):
+        check(self.lib.hcl_halo_pack(self.ptr, int(side), int(width), C.c_void_p(dev_ptr)))
+
+    def halo_unpack(self, side, width, dev_ptr):
+        check(self.lib.hcl_halo_unpack(self.ptr, int(side), int(width), C.c_void_p(dev_ptr)))
+
+    def bytes_per_node(self):
+        return float(self.lib.hcl_mlups_bytes_per_node(self.ptr))
+
+    def destroy(self):
+        if self.ptr:
+            check(self.lib.hcl_destroy(self.ptr))
+            self.ptr = C.c_void_p()
+
+
+class CellType:
+    """hemocell.addCellType<Mechanics>(name, constructType) for one type."""
+
+    def __init__(self, P, model, shape, radius, min_triangles, kLink, kArea, kVolume, kBend, eta_m=0.0,
+                 aspect_ratio=0.3, inner_edges=None):
+        ensure_init()
+        self.lib = capi.lib()
+        M = Material()
+        M.kLink, M.kArea, M.kVolume, M.kBend, M.eta_m = kLink, kArea, kVolume, kBend, eta_m
+        M.radius, M.min_triangles, M.aspect_ratio = radius, int(min_triangles), aspect_ratio
+        self._ie = None
+        if inner_edges is not None and len(inner_edges):
+            self._ie = np.ascontiguousarray(inner_edges, dtype=np.int64)
+            M.inner_edges = lptr(self._ie)
+            M.n_inner = len(self._ie)
+        else:
+            M.inner_edges = None
+            M.n_inner = 0
+        self.ptr = C.c_void_p()
+        check(self.lib.hcp_celltype_create(C.byref(self.ptr), int(model), int(shape), C.byref(P), C.byref(M)))
+        sz = (C.c_int * 4)()
+        check(self.lib.hcp_celltype_sizes(self.ptr, sz))
+        self.nv, self.nt, self.ne, self.nie = [int(x) for x in sz]
+        self.model = model
+
+    @classmethod
+    def rbc(cls, P, **kw):
+        """examples/pipeflow/RBC.xml with RbcHighOrderModel / RBC_FROM_SPHERE"""
+        d = dict(radius=3.91e-6, min_triangles=600, kLink=15.0, kArea=5.0, kVolume=20.0, kBend=80.0, eta_m=0.0)
+        d.update(kw)
+        return cls(P, MODEL_RBC_HO, RBC_FROM_SPHERE, **d)
+
+    @classmethod
+    def plt(cls, P, **kw):
+        """examples/pipeflow/PLT.xml with PltSimpleModel / ELLIPSOID_FROM_SPHERE"""
+        d = dict(radius=1.25e-6, min_triangles=66, kLink=25.0, kArea=8.0, kVolume=100.0, kBend=250.0, eta_m=0.0,
+                 aspect_ratio=0.434782608696, inner_edges=PLT_INNER_EDGES)
+        d.update(kw)
+        return cls(P, MODEL_PLT_SIMPLE, ELLIPSOID_FROM_SPHERE, **d)
+
+    def tables(self):
+        t = dict(vertices=np.empty((self.nv, 3)), triangles=np.empty((self.nt, 3), np.int64),
+                 edges=np.empty((self.ne, 2), np.int64), edge_length_eq=np.empty(self.ne),
+                 edge_angle_eq=np.empty(self.ne), triangle_area_eq=np.empty(self.nt),
+                 vertex_vertexes=np.empty((self.nv, 6), np.int64), patch_dist_eq=np.empty(self.nv),
+                 scalars=np.empty(9))
+        check(self.lib.hcp_celltype_tables(self.ptr, dptr(t["vertices"]), lptr(t["triangles"]), lptr(t["edges"]),
+                                           dptr(t["edge_length_eq"]), dptr(t["edge_angle_eq"]),
+                                           dptr(t["triangle_area_eq"]), lptr(t["vertex_vertexes"]),
+                                           dptr(t["patch_dist_eq"]), dptr(t["scalars"])))
+        names = ("volume_eq", "area_mean_eq", "edge_mean_eq", "angle_mean_eq", "k_volume", "k_area", "k_link",
+                 "k_bend", "eta_m")
+        t.update({n: float(v) for n, v in zip(names, t["scalars"])})
+        return t
+
+    def destroy(self):
+        if self.ptr:
+            check(self.lib.hcp_celltype_destroy(self.ptr))
+            self.ptr = C.c_void_p()
+
+
+class Cells:
+    """HemoCellFields: all membrane vertices on this GPU and the per-phase operations."""
+
+    def __init__(self, lattice, P):
+        self.lib = capi.lib()
+        self.lattice = lattice
+        self.P = P
+        self.ptr = C.c_void_p()
+        check(self.lib.hcp_create(C.byref(self.ptr), lattice.ptr, C.byref(P)))
+        self.types = []
+        self._next_id = 0
+
+    def addCellType(self, celltype, material_timescale=1):
+        idx = C.c_int()
+        check(self.lib.hcp_add_type(self.ptr, celltype.ptr, int(material_timescale), C.byref(idx)))
+        self.types.append(celltype)
+        return idx.value
+
+    def addCell(self, type_index, centre_lu, angles_deg=(0.0, 0.0, 0.0), min_dist_um=0.0, cell_id=None):
+        """one line of a .pos file, already in lattice units; angles in degrees as in the file
+        (io/readPositionsBloodCells.cpp:218-229: rad, then negated)"""
+        c = np.array(centre_lu, dtype=np.float64)
+        a = np.array(angles_deg, dtype=np.float64) * (3.14159265358979323846 / 180.0)
+        a = a * -1.0
+        placed = C.c_int()
+        cid = self._next_id if cell_id is None else int(cell_id)
+        self._next_id = max(self._next_id, cid + 1)
+        check(self.lib.hcp_add_cell(self.ptr, int(type_index), cid, dptr(c), dptr(a), float(min_dist_um), C.byref(placed)))
+        return bool(placed.value)
+
+    def counts(self):
+        nv, nc, nd = C.c_long(), C.c_long(), C.c_long()
+        check(self.lib.hcp_counts(self.ptr, C.byref(nv), C.byref(nc), C.byref(nd)))
+        return nv.value, nc.value, nd.value
+
+    def type_range(self, t):
+        f, n = C.c_long(), C.c_long()
+        check(self.lib.hcp_type_range(self.ptr, int(t), C.byref(f), C.byref(n)))
+        return f.value, n.value
+
+    def _get(self, what):
+        out = np.empty((self.counts()[0], 3), dtype=np.float64)
+        check(self.lib.hcp_download(self.ptr, what, dptr(out)))
+        return out
+
+    def _set(self, what, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.shape == (self.counts()[0], 3)
+        check(self.lib.hcp_upload(self.ptr, what, dptr(a)))
+
+    positions = property(lambda s: s._get(0), lambda s, a: s._set(0, a))
+    velocities = property(lambda s: s._get(1), lambda s, a: s._set(1, a))
+    forces = property(lambda s: s._get(2), lambda s, a: s._set(2, a))
+
+    def cell_ids(self):
+        ids = np.empty(self.counts()[1], dtype=np.int64)
+        check(self.lib.hcp_download_cell_ids(self.ptr, lptr(ids)))
+        return ids
+
+    def addVertexForce(self, vertex_index, f):
+        idx = np.ascontiguousarray(vertex_index, dtype=np.int64)
+        ff = np.ascontiguousarray(f, dtype=np.float64).reshape(len(idx), 3)
+        check(self.lib.hcp_add_vertex_force(self.ptr, lptr(idx), len(idx), dptr(ff)))
+
+    def spreadParticleForce(self, force_limit=True):
+        check(self.lib.hcp_spread(self.ptr, int(force_limit)))
+
+    def interpolateFluidVelocity(self):
+        check(self.lib.hcp_interpolate(self.ptr))
+
+    def advanceParticles(self, check_deletions=True):
+        check(self.lib.hcp_advance(self.ptr, int(check_deletions)))
+
+    def applyConstitutiveModel(self, iter_=0, forced=False):
+        check(self.lib.hcp_mechanics(self.ptr, int(iter_), int(forced)))
+
+    def force_components(self, t):
+        f, n = self.type_range(t)
+        nv = self.types[t].nv
+        comp = np.empty((6, n * nv, 3), dtype=np.float64)
+        check(self.lib.hcp_mechanics_components(self.ptr, int(t), dptr(comp)))
+        return comp
+
+    def cell_info(self, t):
+        f, n = self.type_range(t)
+        vol, area, bbox, cen = np.empty(n), np.empty(n), np.empty((n, 6)), np.empty((n, 3))
+        check(self.lib.hcp_cell_info(self.ptr, int(t), dptr(vol), dptr(area), dptr(bbox), dptr(cen)))
+        return dict(volume=vol, area=area, bbox=bbox, position=cen)
+
+    def destroy(self):
+        if self.ptr:
+            check(self.lib.hcp_destroy(self.ptr))
+            self.ptr = C.c_void_p()
+
+
+class HemoCell:
+    """hemo::HemoCell facade for one GPU (hemocell.h:68-253): owns lattice + cellfields, iterate()."""
+
+    def __init__(self, lattice, P):
+        self.lattice = lattice
+        self.P = P
+        self.cellfields = Cells(lattice, P)
+        self.iter = 0
+        self.particleVelocityUpdateTimescale = 1
+        self.force_limit = True
+        self.deletion_check_every = 1
+
+    def setParticleVelocityUpdateTimeScaleSeparation(self, n):
+        self.particleVelocityUpdateTimescale = int(n)
+
+    def iterate(self, n=1):
+        it = C.c_long(self.iter)
+        check(capi.lib().hc_iterate(self.lattice.ptr, self.cellfields.ptr, C.byref(it), int(n),
+                                    self.particleVelocityUpdateTimescale, int(self.force_limit),
+                                    int(self.deletion_check_every)))
+        self.iter = it.value
+
+    def synchronize(self):
+        check(capi.lib().hc_synchronize())
+
+
+def pipe_mask(nx, ny, nz):
+    """analytic cylinder along x replacing tube.stl: radius (ny-2)/2 centred at
+    ((ny-1)/2,(nz-1)/2); node solid iff r > R"""
+    y = np.arange(ny)[:, None] - (ny - 1) / 2.0
+    z = np.arange(nz)[None, :] - (nz - 1) / 2.0
+    R = (ny - 2) / 2.0
+    solid = (y * y + z * z) > R * R
+    return np.ascontiguousarray(np.broadcast_to(solid[None], (nx, ny, nz)).astype(np.uint8)), R

@@ -1,0 +1,69 @@
+"""x-slab decomposition of the pipe across the GPUs of one node (one process per GPU).
+
+Reference equivalent: Palabos atomic blocks + envelopes (core/hemoCell.cpp:142 fluid envelope,
+core/hemoCellFields.cpp:377-499 syncEnvelopes).  Here every rank owns ONE slab along x (the pipe axis);
+per step it exchanges the x-faces of the population field with its two neighbours (point-to-point, no
+collective), and membrane cells that reach across a slab face are replicated on both ranks like the
+reference's envelope copies, re-synchronised from their owner every stepParticleEvery steps.
+
+world == 1 runs the whole loop inside the library (hc_iterate) with the periodic wrap done in-kernel.
+"""
+import numpy as np
+
+from . import host
+
+
+class SlabRunner:
+    def __init__(self, nx_local, ny, nz, rank, world, P, periodic=(True, False, False), particle_timescale=5,
+                 material_timescale=20, deletion_check_every=1, comm=None):
+        self.rank, self.world = rank, world
+        self.nx, self.ny, self.nz = nx_local, ny, nz
+        self.nx_global = nx_local * world
+        self.x0 = rank * nx_local
+        self.P = P
+        self.periodic = periodic
+        self.k_p, self.k_m = particle_timescale, material_timescale
+        self.lattice = host.Lattice(nx_local, ny, nz, periodic, 1.0 / P.tau, x0=self.x0, nx_global=self.nx_global,
+                                    n_slabs=world)
+        self.hemocell = host.HemoCell(self.lattice, P)
+        self.hemocell.setParticleVelocityUpdateTimeScaleSeparation(particle_timescale)
+        self.hemocell.deletion_check_every = deletion_check_every
+        self.cells = self.hemocell.cellfields
+        self.comm = comm
+        if world > 1:
+            from .exchange import SlabExchange
+            self.exchange = SlabExchange(self, comm)
+        else:
+            self.exchange = None
+
+    def define_bounce_back(self, mask_global):
+        self.lattice.defineBounceBack(mask_global)
+
+    def add_cell_type(self, celltype):
+        return self.cells.addCellType(celltype, self.k_m)
+
+    def load_cells(self, t, centres, angles, min_dist_um=0.0):
+        """place the cells this rank has to hold; returns the number of cells placed on this rank"""
+        if self.exchange is not None:
+            return self.exchange.load_cells(t, centres, angles, min_dist_um)
+        n = 0
+        for i, (c, a) in enumerate(zip(centres, angles)):
+            n += bool(self.cells.addCell(t, c, a, min_dist_um, cell_id=i))
+        return n
+
+    def owned_vertices(self):
+        if self.exchange is not None:
+            return self.exchange.owned_vertices()
+        return self.cells.counts()[0]
+
+    def prepare(self):
+        """what the drivers do before the loop: forces of the initial configuration"""
+        self.cells.applyConstitutiveModel(0, True)
+        if self.exchange is not None:
+            self.exchange.prepare()
+
+    def run(self, n):
+        if self.exchange is None:
+            self.hemocell.iterate(n)
+        else:
+            self.exchange.run(n)

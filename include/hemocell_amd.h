@@ -1,0 +1,170 @@
+/*
+ * hemocell_amd.h -- C ABI of the MI355X-native IB-LBM hot path.
+ *
+ * Drop-in boundary for the one data-parallel path of HemoCell:
+ * the D3Q19 Guo-BGK collide-stream, the phi2 immersed-boundary spread /
+ * interpolate, the Euler vertex advance and the rbcHighOrderModel /
+ * pltSimpleModel membrane forces.  Every entry point names the reference
+ * interface it replaces (file:line relative to the HemoCell tree).  Plain
+ * pointers and sizes only; no C++/torch types cross this boundary.  All
+ * functions return 0 on success and a non-zero code on failure, with the
+ * message available from hc_last_error() (the reference logs and exit(1)s,
+ * e.g. core/hemoCell.cpp:75-78; a library must not, so the host layer above
+ * this ABI does that).  The library is HIP-only: there is no CPU fallback and
+ * every call fails loudly when no gfx950 device is usable.
+ *
+ * Threading / process model: one process per GPU, one hc_* context per process
+ * (core/hemoCell.cpp:75-79 has the same rule).
+ */
+#ifndef HEMOCELL_AMD_H
+#define HEMOCELL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HC_OK 0
+#define HC_ERR_HIP 1
+#define HC_ERR_ARG 2
+#define HC_ERR_STATE 3
+
+#define HC_Q 19
+
+typedef struct hc_lattice hc_lattice;   /* one x-slab of the D3Q19 lattice on this GPU          */
+typedef struct hc_celltype hc_celltype; /* CommonCellConstants + moduli of one cell type         */
+typedef struct hc_cells hc_cells;       /* all membrane vertices held by this GPU (SoA)          */
+
+/* ------------------------------------------------------------------ runtime */
+const char *hc_last_error(void);
+/* selects the HIP device, checks it is gfx950; replaces plb::plbInit (core/hemoCell.cpp:80-86) */
+int hc_init(int device);
+int hc_device_count(int *count);
+/* run every kernel of this library on an existing hipStream_t (e.g. the host framework's current stream); NULL = library stream */
+int hc_set_stream(void *hip_stream);
+int hc_synchronize(void);
+/* per-launch hipEvent timing of the dominant kernel (helper/profiler.h:46-77 "collideAndStream" timer) */
+int hc_profile_enable(int on);
+int hc_profile_read(const char *kernel, double *total_ms, long *launches); /* "collide_stream", "ibm_spread", "ibm_interpolate", "advance", "mechanics" */
+int hc_profile_reset(void);
+
+/* ------------------------------------------------------------------ lattice */
+/* MultiBlockLattice3D<T,DESCRIPTOR>(nx,ny,nz, new GuoExternalForceBGKdynamics(omega))
+ * (examples/pipeflow/pipeflow.cpp:66-71).  nx is the LOCAL slab thickness;
+ * x-halos of width 2 are allocated on both sides.  periodic[0] with
+ * n_slabs==1 wraps in-kernel; with n_slabs>1 the caller exchanges halos
+ * (hcl_halo_pack / hcl_halo_unpack).  x0 = global x of local plane 0. */
+int hcl_create(hc_lattice **out, int nx, int ny, int nz, const int periodic[3], double omega,
+               int x0, int nx_global, int n_slabs);
+int hcl_destroy(hc_lattice *L);
+/* defineDynamics(lattice, flagMatrix, bbox, new BounceBack(1.), 0) (examples/pipeflow/pipeflow.cpp:73):
+ * mask[node]=1 -> full-way bounce-back / isBoundary; node = z + nz*(y + ny*x_local), x_local in [-2, nx+2)
+ * i.e. the array holds (nx+4)*ny*nz bytes including the halo planes. */
+int hcl_set_mask(hc_lattice *L, const uint8_t *mask_with_halo);
+/* HemoCell::latticeEquilibrium(rho,u) + lattice->initialize() (core/hemoCell.cpp:129-133) */
+int hcl_init_equilibrium(hc_lattice *L, double rho, const double u[3]);
+/* setExternalVector(lattice, bbox, forceBeginsAt, F) (core/hemoCell.cpp:369-371, examples/pipeflow/pipeflow.cpp:144-146):
+ * the uniform driving force; the per-node IBM force is kept separately and zeroed by the collide kernel */
+int hcl_set_body_force(hc_lattice *L, const double F[3]);
+/* lattice->collideAndStream() (core/hemoCell.cpp:317), n times (fluid-only stepping; n_slabs==1) */
+int hcl_collide_stream(hc_lattice *L, int nsteps);
+/* one collide-stream of this slab; halos must be current. part: 0 = all planes, 1 = interior planes
+ * (those that do not read halo data), 2 = the boundary planes.  hcl_step_end() flips the buffers. */
+int hcl_collide_stream_part(hc_lattice *L, int part);
+int hcl_step_end(hc_lattice *L);
+/* populations in the reference's own layout: AoS [node][19], node = z + nz*(y + ny*x), values f_i - t_i
+ * as Palabos stores them (post-stream state, i.e. what Cell::operator[] returns after collideAndStream) */
+int hcl_download_populations(hc_lattice *L, double *f_aos);
+int hcl_upload_populations(hc_lattice *L, const double *f_aos);
+/* rho[n] and u[n][3] = Cell::computeVelocity (j/rho + F/2), local bulk nodes */
+int hcl_download_rho_u(hc_lattice *L, double *rho, double *u);
+/* IBM force field currently accumulated (without the body force), [node][3] */
+int hcl_download_ibm_force(hc_lattice *L, double *F);
+int hcl_zero_ibm_force(hc_lattice *L);
+/* halo exchange (Palabos duplicateOverlaps(staticVariables), core/hemoCell.cpp:142).  width = 1 (5
+ * populations per face, enough for one collide-stream) or 2 (full planes, needed before an IBM
+ * interpolation).  side 0 = low-x face, 1 = high-x face.  Buffers are DEVICE pointers of
+ * hcl_halo_doubles(L,width) doubles each. */
+size_t hcl_halo_doubles(const hc_lattice *L, int width);
+int hcl_halo_pack(hc_lattice *L, int side, int width, double *dev_buf);
+int hcl_halo_unpack(hc_lattice *L, int side, int width, const double *dev_buf);
+int hcl_dims(const hc_lattice *L, int dims[3]);
+double hcl_mlups_bytes_per_node(const hc_lattice *L); /* algorithmic bytes per node update of the collide kernel */
+
+/* --------------------------------------------------------------- cell types */
+#define HC_MODEL_RBC_HO 0     /* mechanics/rbcHighOrderModel.cpp */
+#define HC_MODEL_PLT_SIMPLE 1 /* mechanics/pltSimpleModel.cpp    */
+#define HC_SHAPE_RBC_FROM_SPHERE 1       /* config/constant_defaults.h:80 */
+#define HC_SHAPE_ELLIPSOID_FROM_SPHERE 6 /* config/constant_defaults.h:81 */
+
+typedef struct hc_params { /* Parameters::lbm_base_parameters, mechanics/constantConversion.cpp:36-59 */
+  double dx, dt, nu_p, rho_p, kBT_p;
+  double tau, nu_lbm, dm, df, f_limit, kBT_lbm;
+} hc_params;
+int hc_params_base(hc_params *P, double dx, double dt, double nu_p, double rho_p, double kBT_p);
+
+typedef struct hc_material { /* <MaterialModel> of RBC.xml / PLT.xml */
+  double kLink, kArea, kVolume, kBend, eta_m;
+  double radius;       /* [m] */
+  int min_triangles;
+  double aspect_ratio; /* ellipsoid only */
+  const long *inner_edges; /* [n_inner][2] (PLT.xml:14-38) or NULL */
+  int n_inner;
+} hc_material;
+
+/* hemocell.addCellType<Model>(name, constructType) (hemocell.h:122-128): builds the mesh
+ * (helper/meshGeneratingFunctions.hh), CommonCellConstants (mechanics/commonCellConstants.cpp:70-409) and
+ * the moduli (mechanics/cellMechanics.h:50-78), and uploads the tables. */
+int hcp_celltype_create(hc_celltype **out, int model, int shape, const hc_params *P, const hc_material *M);
+int hcp_celltype_destroy(hc_celltype *T);
+/* table sizes: out[0..3] = vertices, triangles, edges, inner edges */
+int hcp_celltype_sizes(const hc_celltype *T, int out[4]);
+/* host copies of the tables for inspection / output writers; any pointer may be NULL */
+int hcp_celltype_tables(const hc_celltype *T, double *vertices /*[nv][3]*/, long *triangles /*[nt][3]*/,
+                        long *edges /*[ne][2]*/, double *edge_length_eq, double *edge_angle_eq,
+                        double *triangle_area_eq, long *vertex_vertexes /*[nv][6]*/, double *patch_dist_eq,
+                        double scalars[9] /* volume_eq, area_mean_eq, edge_mean_eq, angle_mean_eq, k_volume, k_area, k_link, k_bend, eta_m */);
+
+/* ---------------------------------------------------------------- cells */
+/* HemoCellFields / HemoCellParticleField (core/hemoCellFields.h:103-158, core/hemoCellParticleField.h:39-207) */
+int hcp_create(hc_cells **out, hc_lattice *L, const hc_params *P);
+int hcp_destroy(hc_cells *C);
+int hcp_add_type(hc_cells *C, hc_celltype *T, int material_timescale /* setMaterialTimeScaleSeparation */, int *type_index);
+/* loadParticles() (io/readPositionsBloodCells.cpp:290-361) for one cell: centre in lattice units (GLOBAL
+ * coordinates), angles in radians, already negated as :228-229 does.  placed=0 when a vertex falls on /
+ * within min_dist_um of a boundary node (:139-164) and the cell is dropped. */
+int hcp_add_cell(hc_cells *C, int type, long cell_id, const double centre_lu[3], const double angles[3],
+                 double min_dist_um, int *placed);
+int hcp_counts(const hc_cells *C, long *n_vertices, long *n_cells, long *n_deleted);
+int hcp_type_range(const hc_cells *C, int type, long *first_vertex, long *n_cells);
+/* serializeValues_t fields as [n][3] arrays in cell-major order; what: 0 position 1 velocity 2 force */
+int hcp_download(hc_cells *C, int what, double *out);
+int hcp_upload(hc_cells *C, int what, const double *in);
+int hcp_download_cell_ids(hc_cells *C, long *ids);
+/* HemoCellStretch::ForceForcedLsps (helper/hemoCellStretch.cpp:63-78): sv.force += f on listed vertices */
+int hcp_add_vertex_force(hc_cells *C, const long *vertex_index, int n, const double *f /*[n][3]*/);
+/* cellfields->spreadParticleForce() (core/hemoCell.cpp:313 -> core/hemoCellParticleField.cpp:841-863) */
+int hcp_spread(hc_cells *C, int force_limit);
+/* cellfields->interpolateFluidVelocity() (core/hemoCell.cpp:329 -> core/hemoCellParticleField.cpp:819-839) */
+int hcp_interpolate(hc_cells *C);
+/* cellfields->advanceParticles() (core/hemoCell.cpp:342 -> core/hemoCellParticleField.cpp:566-588) */
+int hcp_advance(hc_cells *C, int check_deletions);
+/* cellfields->applyConstitutiveModel(forced) (core/hemoCell.cpp:345 -> core/hemoCellParticleField.cpp:633-675) */
+int hcp_mechanics(hc_cells *C, long iter, int forced);
+/* separate_force_vectors output mode (core/hemoCellParticleField.cpp:590-614): comp = [6][n][3]
+ * (volume, area, bending, link, visc, inner link) for the vertices of one type */
+int hcp_mechanics_components(hc_cells *C, int type, double *comp);
+/* HemoCell::iterate() (core/hemoCell.cpp:299-376) n times, single slab, followed each time by the driver's
+ * body-force re-application (examples/pipeflow/pipeflow.cpp:144-146).  particle_timescale =
+ * setParticleVelocityUpdateTimeScaleSeparation. iter is read and advanced. */
+int hc_iterate(hc_lattice *L, hc_cells *C, long *iter, int n, int particle_timescale, int force_limit,
+               int deletion_check_every);
+/* CellInformationFunctionals (helper/cellInfo.cpp:39-80,140-180): per cell volume, area, bbox[6], centroid[3] */
+int hcp_cell_info(hc_cells *C, int type, double *volume, double *area, double *bbox, double *centroid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -132,8 +132,9 @@ static void collide_bounce_back(double *f) {
  * node, then stream f_i(x+c_i) <- f*_i(x) with periodic wrap
  * (patch/palabos.patch:459-466 implements it as in-place swaps; the net effect
  * is the plain collide -> stream done here with two buffers).  A population
- * whose source lies outside a non-periodic face keeps the node's own
- * post-collision value (only wall/BC nodes sit there in the in-scope cases). */
+ * whose source lies outside a non-periodic face is set to fBar = 0 (only
+ * wall/BC nodes sit on such faces in the in-scope cases, so the value never
+ * reaches a fluid node). */
 void orc_collide_stream(orc_lattice *L) {
   const int nx = L->nx, ny = L->ny, nz = L->nz;
   const long n = (long)nx * ny * nz;
@@ -158,8 +159,7 @@ void orc_collide_stream(orc_lattice *L) {
           if (sx < 0 || sx >= nx) { if (L->periodic[0]) sx = (sx + nx) % nx; else ok = 0; }
           if (sy < 0 || sy >= ny) { if (L->periodic[1]) sy = (sy + ny) % ny; else ok = 0; }
           if (sz < 0 || sz >= nz) { if (L->periodic[2]) sz = (sz + nz) % nz; else ok = 0; }
-          long s = ok ? sz + (long)nz * (sy + (long)ny * sx) : k;
-          L->f[k * ORC_Q + i] = L->ftmp[s * ORC_Q + i];
+          L->f[k * ORC_Q + i] = ok ? L->ftmp[(sz + (long)nz * (sy + (long)ny * sx)) * ORC_Q + i] : 0.0;
         }
       }
 }

@@ -1,0 +1,313 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_populations(rng, n, amp=0.02):
+    # fBar = f - t_i around rest equilibrium (0) with a smooth-ish random perturbation
+    return amp * rng.standard_normal((n, 19)) * np.array(O_T())[None, :]
+
+
+def O_T():
+    return [1 / 3] + [1 / 18] * 3 + [1 / 36] * 6 + [1 / 18] * 3 + [1 / 36] * 6
+
+
+def _both_lattices(orc, gpu, nx, ny, nz, periodic, omega, mask=None):
+    Lo = O.OracleLattice(orc, nx, ny, nz, periodic, omega)
+    Lg = gpu.Lattice(nx, ny, nz, periodic, omega)
+    if mask is not None:
+        Lo.set_mask(mask)
+        Lg.defineBounceBack(mask)
+    return Lo, Lg
+
+
+@pytest.mark.parametrize("periodic", [(1, 1, 1), (1, 0, 0), (0, 0, 0), (0, 1, 1)])
+def test_collide_stream_bit_exact_random_state(orc, gpu, periodic):
+    """fluid-only steps from a random state with a body force: populations identical to the oracle, bit for bit"""
+    rng = np.random.default_rng(7)
+    nx, ny, nz = 12, 10, 14
+    mask = np.zeros((nx, ny, nz), np.uint8)
+    for d, per in enumerate(periodic):
+        if not per:  # walls on non-periodic faces (the only configuration the reference uses)
+            sl = [slice(None)] * 3
+            sl[d] = 0; mask[tuple(sl)] = 1
+            sl[d] = -1; mask[tuple(sl)] = 1
+    mask[5, 4:6, 6:9] = 1  # an obstacle inside
+    Lo, Lg = _both_lattices(orc, gpu, nx, ny, nz, periodic, 1.0 / 0.9, mask)
+    f0 = _random_populations(rng, nx * ny * nz)
+    Lo.f[:] = f0
+    Lg.set_populations(f0)
+    F = (1e-5, -2e-6, 3e-6)
+    Lo.set_force_uniform(F); Lg.setExternalVector(F)
+    np.testing.assert_array_equal(Lg.populations()[mask.reshape(-1) == 0], f0[mask.reshape(-1) == 0])
+    for steps in (1, 9):
+        Lo.collide_stream(steps); Lg.collideAndStream(steps)
+        fo, fg = Lo.f.copy(), Lg.populations()
+        fluid = mask.reshape(-1) == 0
+        assert np.array_equal(fg[fluid], fo[fluid]), np.abs(fg[fluid] - fo[fluid]).max()
+    Lo.destroy(); Lg.destroy()
+
+
+def test_pipe_flow_bit_exact_and_poiseuille(orc, gpu):
+    """body-force driven flow in the analytic cylinder (BounceBack), x periodic: bit-exact vs oracle"""
+    nx, ny, nz = 6, 34, 34
+    mask, R = gpu.pipe_mask(nx, ny, nz)
+    Lo, Lg = _both_lattices(orc, gpu, nx, ny, nz, (1, 0, 0), 1.0 / 1.1, mask)
+    Lo.init_equilibrium(); Lg.latticeEquilibrium(1.0, (0, 0, 0))
+    F = (1e-6, 0, 0)
+    Lo.set_force_uniform(F); Lg.setExternalVector(F)
+    Lo.set_threads(8)
+    Lo.collide_stream(300); Lg.collideAndStream(300)
+    fluid = mask.reshape(-1) == 0
+    fo, fg = Lo.f.copy(), Lg.populations()
+    assert np.array_equal(fg[fluid], fo[fluid])
+    rho, u = Lg.rho_u()
+    ux = u[:, 0].reshape(nx, ny, nz)
+    assert ux[0, ny // 2, nz // 2] > 0 and np.abs(ux[0] - ux[3]).max() < 1e-15
+    Lo.destroy(); Lg.destroy()
+
+
+def _types(orc, gpu, P_o, P_g):
+    To = O.make_rbc(orc, P_o)
+    Tg = gpu.CellType.rbc(P_g)
+    return To, Tg
+
+
+def test_parameters_and_tables_match_oracle(orc, gpu):
+    Po = O.make_params(orc)
+    Pg = gpu.base_parameters()
+    for n, _ in O.Params._fields_:
+        assert getattr(Po, n) == getattr(Pg, n), n
+    for make_o, make_g in ((O.make_rbc, gpu.CellType.rbc), (O.make_plt, gpu.CellType.plt)):
+        To = make_o(orc, Po); Tg = make_g(Pg)
+        t = To.contents; g = Tg.tables()
+        assert (t.nv, t.nt, t.ne) == (Tg.nv, Tg.nt, Tg.ne)
+        for name in ("vertices", "triangles", "edges", "edge_length_eq", "edge_angle_eq", "triangle_area_eq",
+                     "vertex_vertexes", "patch_dist_eq"):
+            assert np.array_equal(t.arr(name), g[name]), name
+        for name in ("volume_eq", "area_mean_eq", "edge_mean_eq", "angle_mean_eq", "k_volume", "k_area", "k_link",
+                     "k_bend", "eta_m"):
+            assert getattr(t, name) == g[name], name
+        orc.orc_celltype_destroy(To); Tg.destroy()
+
+
+def _oracle_forces(orc, T, pos, vel, flags=0x1f, comp=False):
+    nv = T.contents.nv
+    ncell = pos.shape[0] // nv
+    out = np.zeros_like(pos)
+    comps = np.zeros((6, pos.shape[0], 3)) if comp else None
+    for c in range(ncell):
+        p = np.ascontiguousarray(pos[c * nv:(c + 1) * nv]); v = np.ascontiguousarray(vel[c * nv:(c + 1) * nv])
+        f = np.zeros_like(p)
+        if comp:
+            cc = np.zeros((6, nv, 3))
+            orc.orc_cell_forces(T, O.dptr(p), O.dptr(v), O.dptr(f), O.dptr(cc), flags)
+            comps[:, c * nv:(c + 1) * nv] = cc
+        else:
+            orc.orc_cell_forces(T, O.dptr(p), O.dptr(v), O.dptr(f), None, flags)
+        out[c * nv:(c + 1) * nv] = f
+    return (out, comps) if comp else out
+
+
+def _place_cells(gpu, cells, t, centres, angles):
+    for c, a in zip(centres, angles):
+        assert cells.addCell(t, c, a)
+
+
+@pytest.mark.parametrize("kind", ["rbc", "plt", "rbc_visc"])
+def test_membrane_forces_vs_oracle(orc, gpu, kind):
+    """per-vertex membrane forces of deformed cells: RBC bit-exact (gather form reproduces the scatter
+    order), PLT to 1e-12 relative (atan2 is not the same libm)"""
+    rng = np.random.default_rng(11)
+    Po = O.make_params(orc); Pg = gpu.base_parameters()
+    if kind == "plt":
+        To = O.make_plt(orc, Po, eta_m=1e-9); Tg = gpu.CellType.plt(Pg, eta_m=1e-9)
+    elif kind == "rbc_visc":
+        To = O.make_rbc(orc, Po, eta_m=5e-10); Tg = gpu.CellType.rbc(Pg, eta_m=5e-10)
+    else:
+        To = O.make_rbc(orc, Po); Tg = gpu.CellType.rbc(Pg)
+    nx, ny, nz = 64, 40, 40
+    L = gpu.Lattice(nx, ny, nz, (1, 1, 1), 1.0)
+    cells = gpu.Cells(L, Pg)
+    t = cells.addCellType(Tg, 1)
+    centres = [(12.3, 20.1, 19.7), (33.0, 18.4, 22.2), (50.5, 21.0, 17.9)]
+    angles = [(0, 0, 0), (35.0, 10.0, -70.0), (90.0, 45.0, 20.0)]
+    _place_cells(gpu, cells, t, centres, angles)
+    pos = cells.positions
+    pos += 0.05 * rng.standard_normal(pos.shape)
+    vel = 1e-3 * rng.standard_normal(pos.shape)
+    cells.positions = pos; cells.velocities = vel
+    cells.applyConstitutiveModel(0, True)
+    fg = cells.forces
+    fo = _oracle_forces(orc, To, pos, vel)
+    scale = np.abs(fo).max()
+    if kind == "plt":
+        assert np.abs(fg - fo).max() <= 1e-12 * scale
+    else:
+        assert np.array_equal(fg, fo), np.abs(fg - fo).max() / scale
+    # separate force vectors (output mode)
+    comp = cells.force_components(t)
+    _, co = _oracle_forces(orc, To, pos, vel, comp=True)
+    assert np.abs(comp - co).max() <= 1e-12 * scale
+    assert np.abs(comp.sum(0) - fg).max() <= 1e-12 * scale
+    cells.destroy(); L.destroy(); Tg.destroy()
+
+
+def _sim_pair(orc, gpu, nx, ny, nz, periodic, mask, dt=1e-7, plt=False, k_m=1, k_p=1):
+    Po = O.make_params(orc, dt=dt); Pg = gpu.base_parameters(dt=dt)
+    omega = 1.0 / Po.tau
+    Lo, Lg = _both_lattices(orc, gpu, nx, ny, nz, periodic, omega, mask)
+    Lo.init_equilibrium(); Lg.latticeEquilibrium()
+    So = orc.orc_sim_create(Lo.ptr, C.byref(Po))
+    hg = gpu.HemoCell(Lg, Pg)
+    To = O.make_rbc(orc, Po); Tg = gpu.CellType.rbc(Pg)
+    To.contents.timescale = k_m
+    orc.orc_sim_add_type(So, To); hg.cellfields.addCellType(Tg, k_m)
+    if plt:
+        Tpo = O.make_plt(orc, Po); Tpg = gpu.CellType.plt(Pg)
+        Tpo.contents.timescale = k_m
+        orc.orc_sim_add_type(So, Tpo); hg.cellfields.addCellType(Tpg, k_m)
+    So.contents.particle_velocity_timescale = k_p
+    hg.setParticleVelocityUpdateTimeScaleSeparation(k_p)
+    return Po, Lo, Lg, So, hg
+
+
+def _add_both(orc, So, hg, t, centre, angles_deg):
+    c = np.array(centre, dtype=np.float64)
+    a = -np.array(angles_deg, dtype=np.float64) * np.pi / 180.0
+    a_ref = np.array(angles_deg, dtype=np.float64) * (3.14159265358979323846 / 180.0) * -1.0
+    po = orc.orc_sim_add_cell(So, t, O.dptr(c), O.dptr(a_ref), 0.0)
+    pg = hg.cellfields.addCell(t, centre, angles_deg)
+    assert bool(po) == bool(pg)
+    return bool(pg)
+
+
+def _oracle_state(orc, So):
+    n = So.contents.np
+    out = [np.zeros((n, 3)) for _ in range(3)]
+    for w in range(3):
+        orc.orc_sim_get(So, w, O.dptr(out[w]))
+    return out  # pos, vel, force
+
+
+def test_ibm_phases_vs_oracle(orc, gpu):
+    """spread -> collide -> interpolate -> advance -> mechanics, one phase at a time, near walls and across
+    the periodic seam"""
+    nx, ny, nz = 40, 30, 30
+    mask, R = gpu.pipe_mask(nx, ny, nz)
+    Po, Lo, Lg, So, hg = _sim_pair(orc, gpu, nx, ny, nz, (1, 0, 0), mask)
+    assert _add_both(orc, So, hg, 0, (38.5, 14.2, 15.1), (90, 0, 0))     # straddles the periodic seam
+    assert _add_both(orc, So, hg, 0, (18.0, 14.5, 9.6), (90, 20, 0))     # near the wall
+    assert not _add_both(orc, So, hg, 0, (18.0, 14.5, 4.0), (0, 0, 0))   # touches the wall: rejected by both
+    cf = hg.cellfields
+    pos_o, _, _ = _oracle_state(orc, So)
+    assert np.array_equal(cf.positions, pos_o)
+    # deform + initial mechanics
+    rng = np.random.default_rng(3)
+    pos = pos_o + 0.03 * rng.standard_normal(pos_o.shape)
+    orc.orc_sim_set(So, 0, O.dptr(pos)); cf.positions = pos
+    orc.orc_sim_mechanics(So, 1); cf.applyConstitutiveModel(0, True)
+    _, _, f_o = _oracle_state(orc, So)
+    assert np.array_equal(cf.forces, f_o)
+    F = (2e-6, 0, 0)
+    Lo.set_force_uniform(F); Lg.setExternalVector(F)
+    # spread
+    orc.orc_sim_spread(So); cf.spreadParticleForce(True)
+    Fo = Lo.force.copy() - np.array(F)[None, :]
+    Fg = Lg.ibm_force()
+    fluid = mask.reshape(-1) == 0
+    assert np.abs(Fg[fluid] - Fo[fluid]).max() <= 1e-14 * np.abs(Fo).max()
+    assert np.abs(Fg.sum(0) - cf.forces.sum(0)).max() <= 1e-12 * np.abs(cf.forces).sum()
+    # collide + interpolate
+    orc.orc_collide_stream(Lo.ptr); Lg.collideAndStream(1)
+    assert np.abs(Lg.populations()[fluid] - Lo.f[fluid]).max() <= 1e-15
+    orc.orc_sim_interpolate(So); cf.interpolateFluidVelocity()
+    _, v_o, _ = _oracle_state(orc, So)
+    assert np.abs(cf.velocities - v_o).max() <= 1e-13 * np.abs(v_o).max()
+    # advance + mechanics
+    orc.orc_sim_advance(So); cf.advanceParticles(True)
+    p_o, _, _ = _oracle_state(orc, So)
+    assert np.abs(cf.positions - p_o).max() <= 1e-13
+    Lo.destroy(); Lg.destroy()
+
+
+@pytest.mark.parametrize("case", ["pipe_rbc", "pipe_rbc_plt_cadence", "box_periodic"])
+def test_iterate_trajectories_vs_oracle(orc, gpu, case):
+    """HemoCell::iterate for N steps: fluid populations and vertex positions within 1e-6 relative of the
+    oracle (north_star tolerance); in practice ~1e-12 (only the atomic spread order differs)"""
+    if case == "box_periodic":
+        nx, ny, nz = 32, 32, 32
+        periodic = (1, 1, 1); mask = np.zeros((nx, ny, nz), np.uint8); k_m, k_p, plt = 1, 1, False
+        F = (1e-6, 2e-6, -1e-6)
+    else:
+        nx, ny, nz = 48, 34, 34
+        mask, R = gpu.pipe_mask(nx, ny, nz); periodic = (1, 0, 0)
+        plt = case.endswith("cadence"); k_m, k_p = (4, 2) if plt else (1, 1)
+        F = (5e-6, 0, 0)
+    Po, Lo, Lg, So, hg = _sim_pair(orc, gpu, nx, ny, nz, periodic, mask, plt=plt, k_m=k_m, k_p=k_p)
+    assert _add_both(orc, So, hg, 0, (10.0, 16.5, 16.5), (90, 0, 0))
+    assert _add_both(orc, So, hg, 0, (30.0, 16.0, 17.0), (70, 30, 10))
+    if plt:
+        assert _add_both(orc, So, hg, 1, (20.0, 12.0, 20.0), (10, 20, 30))
+        assert _add_both(orc, So, hg, 1, (45.0, 20.0, 13.0), (0, 0, 0))
+    Lo.set_force_uniform(F); Lg.setExternalVector(F)
+    So.contents.body_force[0], So.contents.body_force[1], So.contents.body_force[2] = F
+    Lo.set_threads(8)
+    orc.orc_sim_mechanics(So, 1); hg.cellfields.applyConstitutiveModel(0, True)
+    nsteps = 60
+    for _ in range(nsteps):
+        orc.orc_sim_iterate(So)
+    hg.iterate(nsteps)
+    p_o, v_o, f_o = _oracle_state(orc, So)
+    p_g = hg.cellfields.positions
+    assert hg.iter == So.contents.iter == nsteps
+    assert np.abs(p_g - p_o).max() <= 1e-6 * np.abs(p_o).max()
+    assert np.abs(p_g - p_o).max() <= 1e-9, np.abs(p_g - p_o).max()
+    fluid = mask.reshape(-1) == 0
+    fo, fg = Lo.f[fluid], Lg.populations()[fluid]
+    assert np.abs(fg - fo).max() <= 1e-6 * np.abs(fo).max()
+    assert np.abs(hg.cellfields.forces - f_o).max() <= 1e-6 * np.abs(f_o).max()
+    Lo.destroy(); Lg.destroy()
+
+
+
+def test_stretch_cell_validation_band(orc, gpu):
+    """tests/validation/stretch_cell/test_stretch_cell.cpp:158-162, 25 pN case on the GPU path (bounce-back
+    walls in place of the regularised velocity BC): transverse 7.3-7.9 um, axial 9.2-9.7 um, volume +-2 %"""
+    dt = 1e-7
+    Pg = gpu.base_parameters(dt=dt)
+    nx, ny, nz = 52, 26, 26
+    mask = np.zeros((nx, ny, nz), np.uint8)
+    mask[0] = mask[-1] = 1; mask[:, 0] = mask[:, -1] = 1; mask[:, :, 0] = mask[:, :, -1] = 1
+    L = gpu.Lattice(nx, ny, nz, (0, 0, 0), 1.0 / Pg.tau)
+    L.defineBounceBack(mask); L.latticeEquilibrium()
+    h = gpu.HemoCell(L, Pg)
+    T = gpu.CellType.rbc(Pg)
+    h.cellfields.addCellType(T, 1)
+    um = 1e-6 / Pg.dx
+    assert h.cellfields.addCell(0, (12.0 * um, 6 * um, 6 * um), (90, 0, 0))
+    pos = h.cellfields.positions
+    order = np.argsort(pos[:, 0], kind="stable")
+    lower, upper = order[:7], order[-7:]
+    f = 25.0 * 1e-12 / Pg.df / 7
+    idx = np.concatenate([lower, upper])
+    ff = np.zeros((14, 3)); ff[:7, 0] = -f; ff[7:, 0] = f
+    h.cellfields.applyConstitutiveModel(0, True)
+    info0 = h.cellfields.cell_info(0)
+    for it in range(10000):
+        h.cellfields.addVertexForce(idx, ff)   # cellStretch.applyForce()
+        h.iterate(1)
+    info = h.cellfields.cell_info(0)
+    bb = info["bbox"][0] / um
+    axial, transverse = bb[1] - bb[0], bb[3] - bb[2]
+    assert 7.3 <= transverse <= 7.9, transverse
+    assert 9.2 <= axial <= 9.7, axial
+    assert 0.98 < info["volume"][0] / info0["volume"][0] <= 1.02
+    assert h.cellfields.counts()[1] == 1
+    L.destroy()

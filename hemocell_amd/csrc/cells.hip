@@ -968,7 +968,8 @@ int hcp_mechanics_components(hc_cells *C, int type, double *comp) {
   HC_HIP(hipMalloc((void **)&d, (size_t)(18 * n) * sizeof(double)));
   rc = launch_mechanics(C, type, d);
   if (rc == HC_OK) {
-    hipError_t e = hipMemcpy(comp, d, (size_t)(18 * n) * sizeof(double), hipMemcpyDeviceToHost);
+    hipError_t e = hipStreamSynchronize(hc::stream());  // the library stream is non-blocking
+    if (e == hipSuccess) e = hipMemcpy(comp, d, (size_t)(18 * n) * sizeof(double), hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = hc::hip_fail(e, "hipMemcpy", __FILE__, __LINE__);
   }
   hipFree(d);

@@ -47,9 +47,11 @@ struct hc_cells {
   std::vector<double> hvel[8], hfrc[8];
   std::vector<long> hids[8];
   bool host_dirty = false;       // host staging newer than device
-  long nverts = 0, cap = 0;
+  long nverts = 0, cap = 0;      // live vertices (all types); allocated vertex capacity
   long ncells[8] = {0};
-  long first[8] = {0};           // first vertex of each type on the device
+  long capc[8] = {0};            // per-type capacity in cells (device regions are fixed-size per type)
+  long first[8] = {0};           // first vertex of each type's region on the device
+  long cell0[8] = {0};           // first cell slot of each type's region
   double *pos[3] = {nullptr, nullptr, nullptr}, *vel[3] = {nullptr, nullptr, nullptr}, *frc[3] = {nullptr, nullptr, nullptr};
   int *d_tag = nullptr;          // per-cell deletion tags (all types, slot order)
   long tag_cap = 0;
@@ -94,11 +96,17 @@ struct Stencil {
 // interpolationCoefficientsPhi2 (core/immersedBoundaryMethod.h:62-138).  Per axis only the pair
 // {centre-1, centre} (x < centre) or {centre, centre+1} can carry a non-zero tent weight, and visiting
 // the 2x2x2 pairs in ascending offset order is the reference's 27-node loop with its zero-weight skips.
+__device__ __forceinline__ long nearest_node(double x) { return (long)floor(x + 0.5); }
+
 __device__ __forceinline__ void phi2_stencil(const LatView &v, double px, double py, double pz, Stencil &s) {
-  const double p[3] = {px - (double)v.x0, py, pz};
+  // weights are formed in GLOBAL coordinates (identical bits on every slab that holds a copy of the
+  // vertex); only the node index is made slab-local.  plint(x+0.5) of the reference (:86) truncates,
+  // which equals floor on the block-relative coordinates (>= 0) it is applied to; floor is used so that
+  // a periodic image at negative x picks the same nodes as its wrapped position.
+  const double p[3] = {px, py, pz};
   long c[3]; int d0[3];
 #pragma unroll
-  for (int a = 0; a < 3; a++) { c[a] = (long)(p[a] + 0.5); d0[a] = (p[a] < (double)c[a]) ? -1 : 0; }
+  for (int a = 0; a < 3; a++) { c[a] = nearest_node(p[a]); d0[a] = (p[a] < (double)c[a]) ? -1 : 0; }
   double total = 0.0;
 #pragma unroll
   for (int i = 0; i < 2; i++)
@@ -108,11 +116,11 @@ __device__ __forceinline__ void phi2_stencil(const LatView &v, double px, double
       for (int k = 0; k < 2; k++) {
         const int idx = i * 4 + j * 2 + k;
         const long gx = c[0] + d0[0] + i, gy = c[1] + d0[1] + j, gz = c[2] + d0[2] + k;
-        long lx = gx, ly = gy, lz = gz;
+        long lx = gx - v.x0, ly = gy, lz = gz;
         bool ok = true;
-        if (v.wrap_x) lx = pmod(gx, v.nx);
-        else if (v.halo_x) ok = ok && (gx >= -1 && gx <= v.nx);
-        else ok = ok && (gx >= 0 && gx < v.nx);
+        if (v.wrap_x) lx = pmod(lx, v.nx);
+        else if (v.halo_x) ok = ok && (lx >= -HALO && lx < v.nx + HALO);
+        else ok = ok && (lx >= 0 && lx < v.nx);
         if (gy < 0 || gy >= v.ny) { if (v.per_y) ly = pmod(gy, v.ny); else ok = false; }
         if (gz < 0 || gz >= v.nz) { if (v.per_z) lz = pmod(gz, v.nz); else ok = false; }
         double weight = 0.0; long node = -1;
@@ -223,9 +231,9 @@ __global__ __launch_bounds__(256) void advance_kernel(LatView v, long n, double 
   const double x = px[i] + vx[i], y = py[i] + vy[i], z = pz[i] + vz[i];
   px[i] = x; py[i] = y; pz[i] = z;
   // nearest node is a boundary -> tag (core/hemoCellParticleField.cpp:571-583)
-  long gx = (long)((x - (double)v.x0) + 0.5), gy = (long)(y + 0.5), gz = (long)(z + 0.5);
+  long gx = nearest_node(x) - v.x0, gy = nearest_node(y), gz = nearest_node(z);
   bool inside = true;
-  if (v.wrap_x) gx = pmod(gx, v.nx); else inside = inside && (gx >= (v.halo_x ? -1 : 0) && gx <= (v.halo_x ? v.nx : v.nx - 1));
+  if (v.wrap_x) gx = pmod(gx, v.nx); else inside = inside && (gx >= (v.halo_x ? -HALO : 0) && gx < (v.halo_x ? v.nx + HALO : v.nx));
   if (gy < 0 || gy >= v.ny) { if (v.per_y) gy = pmod(gy, v.ny); else inside = false; }
   if (gz < 0 || gz >= v.nz) { if (v.per_z) gz = pmod(gz, v.nz); else inside = false; }
   if (inside && v.mask[(gx + HALO) * (long)v.plane + gy * v.nz + gz] != 0) {
@@ -505,6 +513,76 @@ __global__ void add_vertex_force_kernel(int n, const long *idx, const double *f,
   fx[v] += f[3 * i]; fy[v] += f[3 * i + 1]; fz[v] += f[3 * i + 2];
 }
 
+// ---------------------------------------------------------------------------- multi-slab cell exchange
+// per-cell [min_x, max_x, number of vertices whose nearest node lies in this slab]
+__global__ __launch_bounds__(256) void cell_extent_kernel(int nv, const double *px, double *out, int x0, int nx) {
+  __shared__ double lo[256], hi[256];
+  __shared__ int own[256];
+  const int tid = threadIdx.x;
+  const long base = (long)blockIdx.x * nv;
+  double a = 1e300, b = -1e300; int o = 0;
+  for (int i = tid; i < nv; i += 256) {
+    const double x = px[base + i]; a = fmin(a, x); b = fmax(b, x);
+    const long gx = nearest_node(x) - x0;
+    o += (gx >= 0 && gx < nx) ? 1 : 0;
+  }
+  lo[tid] = a; hi[tid] = b; own[tid] = o;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) { lo[tid] = fmin(lo[tid], lo[tid + s]); hi[tid] = fmax(hi[tid], hi[tid + s]); own[tid] += own[tid + s]; }
+    __syncthreads();
+  }
+  if (tid == 0) { out[3 * blockIdx.x] = lo[0]; out[3 * blockIdx.x + 1] = hi[0]; out[3 * blockIdx.x + 2] = (double)own[0]; }
+}
+
+struct VertArrays { double *p[3], *v[3], *f[3]; };
+
+// record layout per vertex: pos[3] vel[3] force[3] (the fields of serializeValues_t that change, core/hemoCellParticle.h:45-63)
+__global__ __launch_bounds__(256) void pack_cells_kernel(int nv, const int *slots, VertArrays a, double *buf, double x_shift) {
+  const long src = (long)slots[blockIdx.x] * nv, dst = (long)blockIdx.x * nv;
+  for (int i = threadIdx.x; i < nv; i += 256) {
+    double *r = buf + (dst + i) * 9;
+    r[0] = a.p[0][src + i] + x_shift; r[1] = a.p[1][src + i]; r[2] = a.p[2][src + i];
+    r[3] = a.v[0][src + i]; r[4] = a.v[1][src + i]; r[5] = a.v[2][src + i];
+    r[6] = a.f[0][src + i]; r[7] = a.f[1][src + i]; r[8] = a.f[2][src + i];
+  }
+}
+
+// merge rule of HemoCellParticleField::addParticle (core/hemoCellParticleField.cpp:173-235): a local
+// particle wins over an incoming copy; "local" = its nearest lattice node lies in this slab
+__global__ __launch_bounds__(256) void unpack_cells_kernel(int nv, const int *slots, const int *is_new, VertArrays a, const double *buf,
+                                                           int x0, int nx) {
+  const long dst = (long)slots[blockIdx.x] * nv, src = (long)blockIdx.x * nv;
+  const bool fresh = is_new[blockIdx.x] != 0;
+  for (int i = threadIdx.x; i < nv; i += 256) {
+    bool take = fresh;
+    if (!take) {
+      const long gx = nearest_node(a.p[0][dst + i]) - x0;
+      take = !(gx >= 0 && gx < nx);
+    }
+    if (take) {
+      const double *r = buf + (src + i) * 9;
+      a.p[0][dst + i] = r[0]; a.p[1][dst + i] = r[1]; a.p[2][dst + i] = r[2];
+      a.v[0][dst + i] = r[3]; a.v[1][dst + i] = r[4]; a.v[2][dst + i] = r[5];
+      a.f[0][dst + i] = r[6]; a.f[1][dst + i] = r[7]; a.f[2][dst + i] = r[8];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void move_cells_kernel(int nv, const int *src_slots, const int *dst_slots, VertArrays a) {
+  const long src = (long)src_slots[blockIdx.x] * nv, dst = (long)dst_slots[blockIdx.x] * nv;
+  for (int i = threadIdx.x; i < nv; i += 256)
+    for (int d = 0; d < 3; d++) { a.p[d][dst + i] = a.p[d][src + i]; a.v[d][dst + i] = a.v[d][src + i]; a.f[d][dst + i] = a.f[d][src + i]; }
+}
+
+__global__ __launch_bounds__(256) void owned_count_kernel(long n, const double *px, int x0, int nx, unsigned long long *count) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  int mine = 0;
+  if (i < n) { const long gx = nearest_node(px[i]) - x0; mine = (gx >= 0 && gx < nx) ? 1 : 0; }
+  const unsigned long long b = __ballot(mine);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (unsigned long long)__popcll(b));
+}
+
 __global__ void fill_vert_cell_kernel(long n, int nv, int cell0, long first, int *vert_cell) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -538,6 +616,7 @@ static int free_device_arrays(hc_cells *C) {
   }
   if (C->d_tag) hipFree(C->d_tag);
   C->d_tag = nullptr; C->cap = 0; C->tag_cap = 0;
+  for (int t = 0; t < 8; t++) C->capc[t] = 0;
   if (C->d_vert_cell) hipFree(C->d_vert_cell);
   C->d_vert_cell = nullptr;
   return HC_OK;
@@ -546,31 +625,38 @@ static int free_device_arrays(hc_cells *C) {
 // host staging -> device (after placement, upload or a deletion)
 static int sync_to_device(hc_cells *C) {
   if (!C->host_dirty) return HC_OK;
-  long nverts = 0, ncells = 0;
+  bool grow = false;
+  long nverts = 0;
   for (int t = 0; t < C->ntypes; t++) {
-    C->first[t] = nverts;
     C->ncells[t] = (long)C->hids[t].size();
     nverts += C->ncells[t] * C->types[t]->host.nv;
-    ncells += C->ncells[t];
+    if (C->ncells[t] > C->capc[t]) grow = true;
   }
-  if (nverts > C->cap) {
+  if (grow || C->cap == 0) {
     free_device_arrays(C);
-    C->cap = nverts + nverts / 8 + 1024;
+    long cap = 0, capcells = 0;
+    for (int t = 0; t < C->ntypes; t++) {
+      C->capc[t] = C->ncells[t] + C->ncells[t] / 4 + 64;
+      C->first[t] = cap; C->cell0[t] = capcells;
+      cap += C->capc[t] * C->types[t]->host.nv; capcells += C->capc[t];
+    }
+    C->cap = cap > 0 ? cap : 1;
     for (int d = 0; d < 3; d++) {
       HC_HIP(hipMalloc((void **)&C->pos[d], C->cap * sizeof(double)));
       HC_HIP(hipMalloc((void **)&C->vel[d], C->cap * sizeof(double)));
       HC_HIP(hipMalloc((void **)&C->frc[d], C->cap * sizeof(double)));
     }
     HC_HIP(hipMalloc((void **)&C->d_vert_cell, C->cap * sizeof(int)));
-  }
-  if (ncells + 1 > C->tag_cap) {
-    if (C->d_tag) HC_HIP(hipFree(C->d_tag));
-    C->tag_cap = ncells + ncells / 8 + 64;
+    C->tag_cap = capcells + 1;
     HC_HIP(hipMalloc((void **)&C->d_tag, C->tag_cap * sizeof(int)));
+    for (int t = 0; t < C->ntypes; t++) {
+      const long n = C->capc[t] * C->types[t]->host.nv;
+      hipLaunchKernelGGL(fill_vert_cell_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), n, C->types[t]->host.nv, (int)C->cell0[t], C->first[t], C->d_vert_cell);
+      HC_HIP(hipGetLastError());
+    }
   }
   C->nverts = nverts;
   std::vector<double> tmp;
-  long cell0 = 0;
   for (int t = 0; t < C->ntypes; t++) {
     const long n = C->ncells[t] * C->types[t]->host.nv;
     if (n == 0) continue;
@@ -582,9 +668,6 @@ static int sync_to_device(hc_cells *C) {
         for (long i = 0; i < n; i++) tmp[(size_t)i] = (*src[w])[(size_t)(3 * i + d)];
         HC_HIP(hipMemcpy(dst[w][d] + C->first[t], tmp.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
       }
-    hipLaunchKernelGGL(fill_vert_cell_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), n, C->types[t]->host.nv, (int)cell0, C->first[t], C->d_vert_cell);
-    HC_HIP(hipGetLastError());
-    cell0 += C->ncells[t];
   }
   HC_HIP(hipMemsetAsync(C->d_tag, 0, C->tag_cap * sizeof(int), hc::stream()));
   HC_HIP(hipStreamSynchronize(hc::stream()));
@@ -790,7 +873,7 @@ int hcp_add_cell(hc_cells *C, int type, long cell_id, const double centre_lu[3],
   bool ok = true;
   for (int i = 0; i < nv && ok; i++) {
     const double v[3] = {centre_lu[0] + m[i][0], centre_lu[1] + m[i][1], centre_lu[2] + m[i][2]};
-    const long n[3] = {(int)(v[0] + 0.5), (int)(v[1] + 0.5), (int)(v[2] + 0.5)};
+    const long n[3] = {(long)std::floor(v[0] + 0.5), (long)std::floor(v[1] + 0.5), (long)std::floor(v[2] + 0.5)};  // int(vertex+0.5), :135
     if (is_boundary(n[0], n[1], n[2])) { ok = false; break; }
     for (int a = -deny; a <= deny && ok; a++) for (int b = -deny; b <= deny && ok; b++) for (int c = -deny; c <= deny; c++)
       if (is_boundary(n[0] + a, n[1] + b, n[2] + c)) { ok = false; break; }
@@ -860,11 +943,21 @@ int hcp_add_vertex_force(hc_cells *C, const long *vertex_index, int n, const dou
   HC_REQUIRE(C && vertex_index && f && n >= 0, "hcp_add_vertex_force: bad arguments");
   if (n == 0) return HC_OK;
   int rc = sync_to_device(C); if (rc != HC_OK) return rc;
-  for (int i = 0; i < n; i++) HC_REQUIRE(vertex_index[i] >= 0 && vertex_index[i] < C->nverts, "hcp_add_vertex_force: vertex index out of range");
+  // vertex_index counts vertices in download order (types packed back to back); device regions have gaps
+  std::vector<long> dev_idx((size_t)n);
+  for (int i = 0; i < n; i++) {
+    long v = vertex_index[i], packed0 = 0; bool found = false;
+    for (int t = 0; t < C->ntypes && !found; t++) {
+      const long nt = C->ncells[t] * C->types[t]->host.nv;
+      if (v >= packed0 && v < packed0 + nt) { dev_idx[(size_t)i] = C->first[t] + (v - packed0); found = true; }
+      packed0 += nt;
+    }
+    HC_REQUIRE(found, "hcp_add_vertex_force: vertex index out of range");
+  }
   long *d_idx = nullptr; double *d_f = nullptr;
   HC_HIP(hipMalloc((void **)&d_idx, n * sizeof(long)));
   HC_HIP(hipMalloc((void **)&d_f, 3 * n * sizeof(double)));
-  HC_HIP(hipMemcpyAsync(d_idx, vertex_index, n * sizeof(long), hipMemcpyHostToDevice, hc::stream()));
+  HC_HIP(hipMemcpyAsync(d_idx, dev_idx.data(), n * sizeof(long), hipMemcpyHostToDevice, hc::stream()));
   HC_HIP(hipMemcpyAsync(d_f, f, 3 * n * sizeof(double), hipMemcpyHostToDevice, hc::stream()));
   hipLaunchKernelGGL(add_vertex_force_kernel, dim3((n + 255) / 256), dim3(256), 0, hc::stream(), n, (const long *)d_idx, (const double *)d_f, C->frc[0], C->frc[1], C->frc[2]);
   HC_HIP(hipGetLastError());
@@ -879,10 +972,14 @@ int hcp_spread(hc_cells *C, int force_limit) {
   if (C->nverts == 0) return HC_OK;
   hc::ProfScope prof(hc::PK_SPREAD);
   const LatView v = make_view(C->L);
-  hipLaunchKernelGGL(ibm_spread_kernel, dim3((unsigned)((C->nverts + 255) / 256)), dim3(256), 0, hc::stream(), v, C->nverts,
-                     (const double *)C->pos[0], (const double *)C->pos[1], (const double *)C->pos[2], C->frc[0], C->frc[1], C->frc[2],
-                     C->L->force[C->L->fcur], force_limit, C->P.f_limit);
-  HC_HIP(hipGetLastError());
+  for (int t = 0; t < C->ntypes; t++) {
+    const long n = C->ncells[t] * C->types[t]->host.nv, f = C->first[t];
+    if (n == 0) continue;
+    hipLaunchKernelGGL(ibm_spread_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), v, n,
+                       (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
+                       C->frc[0] + f, C->frc[1] + f, C->frc[2] + f, C->L->force[C->L->fcur], force_limit, C->P.f_limit);
+    HC_HIP(hipGetLastError());
+  }
   return HC_OK;
 }
 
@@ -895,9 +992,14 @@ int hcp_interpolate(hc_cells *C) {
   const LatView v = make_view(L);
   // state after hcl_step_end: f[cur] holds the populations just written, force[1-fcur] the force they were collided with
   PopView pv{L->f[L->cur], L->force[1 - L->fcur], L->body[0], L->body[1], L->body[2]};
-  hipLaunchKernelGGL(ibm_interpolate_kernel, dim3((unsigned)((C->nverts + 255) / 256)), dim3(256), 0, hc::stream(), v, pv, C->nverts,
-                     (const double *)C->pos[0], (const double *)C->pos[1], (const double *)C->pos[2], C->vel[0], C->vel[1], C->vel[2]);
-  HC_HIP(hipGetLastError());
+  for (int t = 0; t < C->ntypes; t++) {
+    const long n = C->ncells[t] * C->types[t]->host.nv, f = C->first[t];
+    if (n == 0) continue;
+    hipLaunchKernelGGL(ibm_interpolate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), v, pv, n,
+                       (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
+                       C->vel[0] + f, C->vel[1] + f, C->vel[2] + f);
+    HC_HIP(hipGetLastError());
+  }
   return HC_OK;
 }
 
@@ -906,24 +1008,20 @@ static int purge_tagged(hc_cells *C) {
   HC_HIP(hipMemcpyAsync(C->h_ntag, C->d_ntag, sizeof(int), hipMemcpyDeviceToHost, hc::stream()));
   HC_HIP(hipStreamSynchronize(hc::stream()));
   if (*C->h_ntag == 0) return HC_OK;
-  long ncells = 0;
-  for (int t = 0; t < C->ntypes; t++) ncells += C->ncells[t];
-  std::vector<int> tags((size_t)ncells);
-  HC_HIP(hipMemcpy(tags.data(), C->d_tag, (size_t)ncells * sizeof(int), hipMemcpyDeviceToHost));
+  std::vector<int> tags((size_t)C->tag_cap);
+  HC_HIP(hipMemcpy(tags.data(), C->d_tag, (size_t)C->tag_cap * sizeof(int), hipMemcpyDeviceToHost));
   int rc = sync_to_host(C); if (rc != HC_OK) return rc;
-  long cell0 = 0;
   for (int t = 0; t < C->ntypes; t++) {
     const long nc = C->ncells[t]; const int nv = C->types[t]->host.nv;
     std::vector<double> np, nvl, nf; std::vector<long> nid;
     for (long c = 0; c < nc; c++) {
-      if (tags[(size_t)(cell0 + c)]) { C->n_deleted++; continue; }
+      if (tags[(size_t)(C->cell0[t] + c)]) { C->n_deleted++; continue; }
       np.insert(np.end(), C->hpos[t].begin() + 3 * c * nv, C->hpos[t].begin() + 3 * (c + 1) * nv);
       nvl.insert(nvl.end(), C->hvel[t].begin() + 3 * c * nv, C->hvel[t].begin() + 3 * (c + 1) * nv);
       nf.insert(nf.end(), C->hfrc[t].begin() + 3 * c * nv, C->hfrc[t].begin() + 3 * (c + 1) * nv);
       nid.push_back(C->hids[t][(size_t)c]);
     }
     C->hpos[t].swap(np); C->hvel[t].swap(nvl); C->hfrc[t].swap(nf); C->hids[t].swap(nid);
-    cell0 += nc;
   }
   *C->h_ntag = 0;
   HC_HIP(hipMemset(C->d_ntag, 0, sizeof(int)));
@@ -938,10 +1036,14 @@ int hcp_advance(hc_cells *C, int check_deletions) {
   {
     hc::ProfScope prof(hc::PK_ADVANCE);
     const LatView v = make_view(C->L);
-    hipLaunchKernelGGL(advance_kernel, dim3((unsigned)((C->nverts + 255) / 256)), dim3(256), 0, hc::stream(), v, C->nverts, C->pos[0], C->pos[1],
-                       C->pos[2], (const double *)C->vel[0], (const double *)C->vel[1], (const double *)C->vel[2], (const int *)C->d_vert_cell,
-                       C->d_tag, C->d_ntag);
-    HC_HIP(hipGetLastError());
+    for (int t = 0; t < C->ntypes; t++) {
+      const long n = C->ncells[t] * C->types[t]->host.nv, f = C->first[t];
+      if (n == 0) continue;
+      hipLaunchKernelGGL(advance_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), v, n, C->pos[0] + f, C->pos[1] + f,
+                         C->pos[2] + f, (const double *)(C->vel[0] + f), (const double *)(C->vel[1] + f), (const double *)(C->vel[2] + f),
+                         (const int *)(C->d_vert_cell + f), C->d_tag, C->d_ntag);
+      HC_HIP(hipGetLastError());
+    }
   }
   if (check_deletions) return purge_tagged(C);
   return HC_OK;
@@ -1014,6 +1116,148 @@ int hc_iterate(hc_lattice *L, hc_cells *C, long *iter, int n, int particle_times
     if ((rc = hcp_mechanics(C, it, 0)) != HC_OK) return rc;                     // :345
     *iter = it + 1;                                                             // :374 (force zeroing is fused into the collide kernel)
   }
+  return HC_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------- multi-slab cell exchange (host side)
+static VertArrays vert_arrays(hc_cells *C, int t) {
+  VertArrays a;
+  for (int d = 0; d < 3; d++) { a.p[d] = C->pos[d] + C->first[t]; a.v[d] = C->vel[d] + C->first[t]; a.f[d] = C->frc[d] + C->first[t]; }
+  return a;
+}
+static int upload_ints(int **d, const int *h, int n) {
+  HC_HIP(hipMalloc((void **)d, (size_t)(n > 0 ? n : 1) * sizeof(int)));
+  if (n > 0) HC_HIP(hipMemcpyAsync(*d, h, (size_t)n * sizeof(int), hipMemcpyHostToDevice, hc::stream()));
+  return HC_OK;
+}
+
+extern "C" {
+
+int hcp_cell_extents(hc_cells *C, int type, double *minmax) {
+  HC_REQUIRE(C && minmax && type >= 0 && type < C->ntypes, "hcp_cell_extents: bad arguments");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  const long nc = C->ncells[type];
+  if (nc == 0) return HC_OK;
+  double *d = nullptr;
+  HC_HIP(hipMalloc((void **)&d, (size_t)(3 * nc) * sizeof(double)));
+  hipLaunchKernelGGL(cell_extent_kernel, dim3((unsigned)nc), dim3(256), 0, hc::stream(), C->types[type]->host.nv, (const double *)(C->pos[0] + C->first[type]), d, C->L->x0, C->L->nx);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(minmax, d, (size_t)(3 * nc) * sizeof(double), hipMemcpyDeviceToHost, hc::stream());
+  if (e == hipSuccess) e = hipStreamSynchronize(hc::stream());
+  hipFree(d);
+  if (e != hipSuccess) return hc::hip_fail(e, "hcp_cell_extents", __FILE__, __LINE__);
+  return HC_OK;
+}
+
+size_t hcp_record_doubles(const hc_cells *C, int type) {
+  if (!C || type < 0 || type >= C->ntypes) return 0;
+  return (size_t)C->types[type]->host.nv * 9;
+}
+
+int hcp_pack_cells(hc_cells *C, int type, const int *slots, int n, double x_shift, double *dev_buf) {
+  HC_REQUIRE(C && type >= 0 && type < C->ntypes && n >= 0, "hcp_pack_cells: bad arguments");
+  if (n == 0) return HC_OK;
+  HC_REQUIRE(slots && dev_buf, "hcp_pack_cells: null pointer");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  for (int i = 0; i < n; i++) HC_REQUIRE(slots[i] >= 0 && slots[i] < C->ncells[type], "hcp_pack_cells: slot out of range");
+  int *d_slots = nullptr;
+  rc = upload_ints(&d_slots, slots, n); if (rc != HC_OK) return rc;
+  hipLaunchKernelGGL(pack_cells_kernel, dim3((unsigned)n), dim3(256), 0, hc::stream(), C->types[type]->host.nv, (const int *)d_slots, vert_arrays(C, type), dev_buf, x_shift);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(hc::stream());
+  hipFree(d_slots);
+  if (e != hipSuccess) return hc::hip_fail(e, "hcp_pack_cells", __FILE__, __LINE__);
+  return HC_OK;
+}
+
+int hcp_unpack_cells(hc_cells *C, int type, const int *slots, const long *cell_ids, const int *is_new, int n, const double *dev_buf) {
+  HC_REQUIRE(C && type >= 0 && type < C->ntypes && n >= 0, "hcp_unpack_cells: bad arguments");
+  if (n == 0) return HC_OK;
+  HC_REQUIRE(slots && cell_ids && is_new && dev_buf, "hcp_unpack_cells: null pointer");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  long n_new = 0;
+  for (int i = 0; i < n; i++) {
+    if (is_new[i]) { HC_REQUIRE(slots[i] == C->ncells[type] + n_new, "hcp_unpack_cells: new cells must be appended in slot order"); n_new++; }
+    else HC_REQUIRE(slots[i] >= 0 && slots[i] < C->ncells[type], "hcp_unpack_cells: slot out of range");
+  }
+  if (C->ncells[type] + n_new > C->capc[type]) {
+    // slow path: grow the device regions through the host staging
+    rc = sync_to_host(C); if (rc != HC_OK) return rc;
+    const size_t add = (size_t)n_new * C->types[type]->host.nv * 3;
+    C->hpos[type].resize(C->hpos[type].size() + add, 0.0); C->hvel[type].resize(C->hvel[type].size() + add, 0.0); C->hfrc[type].resize(C->hfrc[type].size() + add, 0.0);
+    for (int i = 0; i < n; i++) if (is_new[i]) C->hids[type].push_back(cell_ids[i]);
+    C->host_dirty = true;
+    rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  } else {
+    for (int i = 0; i < n; i++) if (is_new[i]) C->hids[type].push_back(cell_ids[i]);
+    C->ncells[type] += n_new;
+    C->nverts += n_new * C->types[type]->host.nv;
+  }
+  int *d_slots = nullptr, *d_new = nullptr;
+  rc = upload_ints(&d_slots, slots, n); if (rc != HC_OK) return rc;
+  rc = upload_ints(&d_new, is_new, n); if (rc != HC_OK) return rc;
+  hipLaunchKernelGGL(unpack_cells_kernel, dim3((unsigned)n), dim3(256), 0, hc::stream(), C->types[type]->host.nv, (const int *)d_slots, (const int *)d_new,
+                     vert_arrays(C, type), dev_buf, C->L->x0, C->L->nx);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(hc::stream());
+  hipFree(d_slots); hipFree(d_new);
+  if (e != hipSuccess) return hc::hip_fail(e, "hcp_unpack_cells", __FILE__, __LINE__);
+  return HC_OK;
+}
+
+int hcp_remove_cells(hc_cells *C, int type, const int *slots, int n) {
+  HC_REQUIRE(C && type >= 0 && type < C->ntypes && n >= 0, "hcp_remove_cells: bad arguments");
+  if (n == 0) return HC_OK;
+  HC_REQUIRE(slots, "hcp_remove_cells: null pointer");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  const long nc = C->ncells[type], new_nc = nc - n;
+  std::vector<char> dead((size_t)nc, 0);
+  for (int i = 0; i < n; i++) { HC_REQUIRE(slots[i] >= 0 && slots[i] < nc && !dead[(size_t)slots[i]], "hcp_remove_cells: bad slot list"); dead[(size_t)slots[i]] = 1; }
+  // holes below new_nc are filled with the live cells at and above new_nc (disjoint ranges: no hazard)
+  std::vector<int> src, dst;
+  long tail = new_nc;
+  for (long h = 0; h < new_nc; h++) {
+    if (!dead[(size_t)h]) continue;
+    while (tail < nc && dead[(size_t)tail]) tail++;
+    src.push_back((int)tail); dst.push_back((int)h);
+    C->hids[type][(size_t)h] = C->hids[type][(size_t)tail];
+    tail++;
+  }
+  C->hids[type].resize((size_t)new_nc);
+  if (!src.empty()) {
+    int *d_src = nullptr, *d_dst = nullptr;
+    rc = upload_ints(&d_src, src.data(), (int)src.size()); if (rc != HC_OK) return rc;
+    rc = upload_ints(&d_dst, dst.data(), (int)dst.size()); if (rc != HC_OK) return rc;
+    hipLaunchKernelGGL(move_cells_kernel, dim3((unsigned)src.size()), dim3(256), 0, hc::stream(), C->types[type]->host.nv, (const int *)d_src, (const int *)d_dst, vert_arrays(C, type));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(hc::stream());
+    hipFree(d_src); hipFree(d_dst);
+    if (e != hipSuccess) return hc::hip_fail(e, "hcp_remove_cells", __FILE__, __LINE__);
+  }
+  C->ncells[type] = new_nc;
+  C->nverts -= (long)n * C->types[type]->host.nv;
+  return HC_OK;
+}
+
+int hcp_owned_vertices(hc_cells *C, long *n_owned) {
+  HC_REQUIRE(C && n_owned, "hcp_owned_vertices: null pointer");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  unsigned long long *d = nullptr, h = 0;
+  HC_HIP(hipMalloc((void **)&d, sizeof(unsigned long long)));
+  HC_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), hc::stream()));
+  for (int t = 0; t < C->ntypes; t++) {
+    const long n = C->ncells[t] * C->types[t]->host.nv;
+    if (n == 0) continue;
+    hipLaunchKernelGGL(owned_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), n, (const double *)(C->pos[0] + C->first[t]), C->L->x0, C->L->nx, d);
+  }
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, hc::stream());
+  if (e == hipSuccess) e = hipStreamSynchronize(hc::stream());
+  hipFree(d);
+  if (e != hipSuccess) return hc::hip_fail(e, "hcp_owned_vertices", __FILE__, __LINE__);
+  *n_owned = (long)h;
   return HC_OK;
 }
 

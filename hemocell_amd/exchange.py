@@ -1,0 +1,334 @@
+"""Neighbour exchange for x-slab runs (world_size > 1): population halos and particle envelopes.
+
+Reference equivalents
+  * fluid:     Palabos duplicateOverlaps(staticVariables) inside collideAndStream (core/hemoCell.cpp:317,
+               envelope width core/hemoCell.cpp:142) -> halo_exchange()
+  * particles: HemoCellFields::syncEnvelopes (core/hemoCellFields.cpp:377-499): every block that holds >= 1
+               vertex of a cell gets the complete cell; the copy of a vertex owned by the sending block
+               overwrites a non-local copy (HemoCellParticleField::addParticle,
+               core/hemoCellParticleField.cpp:173-235); periodic images are shifted by the domain length
+               (core/hemoCellParticleDataTransfer.cpp:33-65) -> sync_cells()
+
+Only point-to-point messages between x-neighbours are used (no collective on the data path).  The protocol is
+written against a small engine interface so that it runs unchanged on the HIP engine (product) and on a
+numpy stand-in used by the CPU gloo tests of the protocol itself.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import host
+
+E_SHARE = 4.0   # a cell within this many lattice units of a face is replicated on the neighbour
+
+
+class NeighbourComm:
+    """ring of ranks along x; tensors are exchanged with the low (-x) and high (+x) neighbour"""
+
+    def __init__(self, rank, world, periodic, group=None):
+        self.rank, self.world, self.periodic = rank, world, bool(periodic)
+        self.group = group
+        self.lo = (rank - 1) % world if (periodic or rank > 0) else None
+        self.hi = (rank + 1) % world if (periodic or rank < world - 1) else None
+        self.backend = dist.get_backend(group)
+
+    def _stage(self, t):
+        return t if self.backend == "nccl" else t.cpu()
+
+    def exchange(self, send_lo, send_hi, recv_lo, recv_hi):
+        """send_lo goes to the low neighbour (which receives it as its recv_hi) and vice versa.
+        Returns a callable that completes the transfers into recv_lo / recv_hi."""
+        ops, post = [], []
+        s_lo = self._stage(send_lo) if (self.lo is not None and send_lo is not None) else None
+        s_hi = self._stage(send_hi) if (self.hi is not None and send_hi is not None) else None
+        r_lo = (recv_lo if self.backend == "nccl" else torch.empty(recv_lo.shape, dtype=recv_lo.dtype)) if (self.lo is not None and recv_lo is not None) else None
+        r_hi = (recv_hi if self.backend == "nccl" else torch.empty(recv_hi.shape, dtype=recv_hi.dtype)) if (self.hi is not None and recv_hi is not None) else None
+        # order matters when lo and hi are the same peer (world == 2): my lo-face message is the peer's
+        # hi-halo message, so receives are posted hi first
+        if s_lo is not None:
+            ops.append(dist.P2POp(dist.isend, s_lo, self.lo, self.group, tag=1))
+        if s_hi is not None:
+            ops.append(dist.P2POp(dist.isend, s_hi, self.hi, self.group, tag=2))
+        if r_hi is not None:
+            ops.append(dist.P2POp(dist.irecv, r_hi, self.hi, self.group, tag=1))
+        if r_lo is not None:
+            ops.append(dist.P2POp(dist.irecv, r_lo, self.lo, self.group, tag=2))
+        works = dist.batch_isend_irecv(ops) if ops else []
+
+        def wait():
+            for w in works:
+                w.wait()
+            if self.backend != "nccl":
+                if r_lo is not None:
+                    recv_lo.copy_(r_lo)
+                if r_hi is not None:
+                    recv_hi.copy_(r_hi)
+        return wait
+
+
+class HipEngine:
+    """the product engine: every method is one call into libhemocell_amd.so"""
+
+    def __init__(self, lattice, cells, device):
+        self.L, self.C, self.device = lattice, cells, device
+        self.lib = host.capi.lib()
+        self.nx, self.x0, self.nx_global = lattice.nx, lattice.x0, lattice.nx_global
+
+    # ---- fluid
+    def halo_buffer(self, width):
+        return torch.empty(self.L.halo_doubles(width), dtype=torch.float64, device=self.device)
+
+    def halo_pack(self, side, width, buf):
+        self.L.halo_pack(side, width, buf.data_ptr())
+
+    def halo_unpack(self, side, width, buf):
+        self.L.halo_unpack(side, width, buf.data_ptr())
+
+    def collide(self, part):
+        self.L.collide_part(part)
+
+    def step_end(self):
+        self.L.step_end()
+
+    # ---- cells
+    def n_types(self):
+        return len(self.C.types)
+
+    def nv(self, t):
+        return self.C.types[t].nv
+
+    def cell_ids(self, t):
+        ids = self.C.cell_ids()
+        f = sum(self.C.type_range(u)[1] for u in range(t))
+        return ids[f:f + self.C.type_range(t)[1]]
+
+    def cell_extents(self, t):
+        import ctypes as C
+        n = self.C.type_range(t)[1]
+        ext = np.empty((n, 3), dtype=np.float64)
+        host.check(self.lib.hcp_cell_extents(self.C.ptr, t, host.dptr(ext)))
+        return ext
+
+    def pack_cells(self, t, slots, x_shift):
+        import ctypes as C
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        buf = torch.empty(len(slots) * self.nv(t) * 9, dtype=torch.float64, device=self.device)
+        host.check(self.lib.hcp_pack_cells(self.C.ptr, t, slots.ctypes.data_as(host.capi.c_int_p), len(slots), float(x_shift),
+                                           C.c_void_p(buf.data_ptr())))
+        return buf
+
+    def unpack_cells(self, t, slots, ids, is_new, buf):
+        import ctypes as C
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        is_new = np.ascontiguousarray(is_new, dtype=np.int32)
+        host.check(self.lib.hcp_unpack_cells(self.C.ptr, t, slots.ctypes.data_as(host.capi.c_int_p), host.lptr(ids),
+                                             is_new.ctypes.data_as(host.capi.c_int_p), len(slots), C.c_void_p(buf.data_ptr())))
+
+    def remove_cells(self, t, slots):
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        host.check(self.lib.hcp_remove_cells(self.C.ptr, t, slots.ctypes.data_as(host.capi.c_int_p), len(slots)))
+
+    def record_buffer(self, t, n):
+        return torch.empty(n * self.nv(t) * 9, dtype=torch.float64, device=self.device)
+
+    def spread(self):
+        self.C.spreadParticleForce(True)
+
+    def interpolate(self):
+        self.C.interpolateFluidVelocity()
+
+    def advance(self):
+        self.C.advanceParticles(False)
+
+    def mechanics(self, it, forced=False):
+        self.C.applyConstitutiveModel(it, forced)
+
+    def owned_vertices(self):
+        import ctypes as C
+        n = C.c_long()
+        host.check(self.lib.hcp_owned_vertices(self.C.ptr, C.byref(n)))
+        return n.value
+
+
+class SlabProtocol:
+    """the per-step choreography of a multi-slab run; engine-agnostic"""
+
+    def __init__(self, engine, comm, particle_timescale, nx_global, periodic_x, overlap=True):
+        self.e, self.comm = engine, comm
+        self.k_p = particle_timescale
+        self.nx_global, self.periodic_x = nx_global, periodic_x
+        self.iter = 0
+        self.halo_fresh = False
+        self.overlap = overlap
+        self._hb = {}
+        self.stats = {"cells_sent": 0, "cells_new": 0, "cells_dropped": 0}
+
+    # ------------------------------------------------------------------ fluid halos
+    def _bufs(self, width):
+        if width not in self._hb:
+            self._hb[width] = [self.e.halo_buffer(width) for _ in range(4)]
+        return self._hb[width]
+
+    def halo_exchange_begin(self, width):
+        s_lo, s_hi, r_lo, r_hi = self._bufs(width)
+        if self.comm.lo is not None:
+            self.e.halo_pack(0, width, s_lo)
+        if self.comm.hi is not None:
+            self.e.halo_pack(1, width, s_hi)
+        wait = self.comm.exchange(s_lo, s_hi, r_lo, r_hi)
+
+        def finish():
+            wait()
+            if self.comm.lo is not None:
+                self.e.halo_unpack(0, width, r_lo)
+            if self.comm.hi is not None:
+                self.e.halo_unpack(1, width, r_hi)
+        return finish
+
+    # ------------------------------------------------------------------ particle envelopes
+    def sync_cells(self):
+        e, comm = self.e, self.comm
+        x0, x1 = e.x0, e.x0 + e.nx
+        for t in range(e.n_types()):
+            ext = e.cell_extents(t)
+            ids = np.asarray(e.cell_ids(t), dtype=np.int64)
+            n = len(ids)
+            send = {}
+            for side, nb in ((0, comm.lo), (1, comm.hi)):
+                if nb is None:
+                    send[side] = (np.zeros(0, np.int32), np.zeros(0, np.int64))
+                    continue
+                touch = (ext[:, 0] < x0 + E_SHARE) if side == 0 else (ext[:, 1] >= x1 - E_SHARE)
+                # only a rank that owns part of the cell forwards it (a pure ghost is the neighbour's business)
+                touch &= ext[:, 2] > 0
+                slots = np.nonzero(touch)[0].astype(np.int32)
+                order = np.argsort(ids[slots], kind="stable")
+                slots = slots[order]
+                send[side] = (slots, ids[slots])
+            # phase 1: counts
+            cnt_s = [torch.tensor([len(send[s][0])], dtype=torch.int64, device=self._dev()) for s in (0, 1)]
+            cnt_r = [torch.zeros(1, dtype=torch.int64, device=self._dev()) for _ in (0, 1)]
+            comm.exchange(cnt_s[0], cnt_s[1], cnt_r[0], cnt_r[1])()
+            n_lo = int(cnt_r[0].item()) if comm.lo is not None else 0
+            n_hi = int(cnt_r[1].item()) if comm.hi is not None else 0
+            # phase 2: ids + records
+            shift_lo = float(self.nx_global) if (self.periodic_x and comm.rank == 0) else 0.0          # crossing the seam downward
+            shift_hi = -float(self.nx_global) if (self.periodic_x and comm.rank == comm.world - 1) else 0.0
+            ids_s = [torch.from_numpy(np.ascontiguousarray(send[s][1])).to(self._dev()) for s in (0, 1)]
+            ids_r = [torch.zeros(n_lo, dtype=torch.int64, device=self._dev()), torch.zeros(n_hi, dtype=torch.int64, device=self._dev())]
+            rec_s = [e.pack_cells(t, send[0][0], shift_lo), e.pack_cells(t, send[1][0], shift_hi)]
+            rec_r = [e.record_buffer(t, n_lo), e.record_buffer(t, n_hi)]
+            w1 = comm.exchange(ids_s[0], ids_s[1], ids_r[0], ids_r[1])
+            w1()
+            w2 = comm.exchange(rec_s[0], rec_s[1], rec_r[0], rec_r[1])
+            w2()
+            self.stats["cells_sent"] += len(send[0][0]) + len(send[1][0])
+            # phase 3: merge
+            slot_of = {int(i): k for k, i in enumerate(ids)}
+            refreshed = np.zeros(n, dtype=bool)
+            n_now = n
+            for side, cnt in ((0, n_lo), (1, n_hi)):
+                if cnt == 0:
+                    continue
+                rid = ids_r[side].cpu().numpy()
+                slots = np.empty(cnt, np.int32); is_new = np.zeros(cnt, np.int32)
+                for k, cid in enumerate(rid):
+                    s = slot_of.get(int(cid))
+                    if s is None:
+                        s = n_now; n_now += 1
+                        slot_of[int(cid)] = s
+                        is_new[k] = 1
+                        self.stats["cells_new"] += 1
+                    elif s < n:
+                        refreshed[s] = True
+                    slots[k] = s
+                e.unpack_cells(t, slots, rid, is_new, rec_r[side])
+            # phase 4: a copy without any local vertex survives only while its owner keeps refreshing it
+            # (deleteNonLocalParticles, core/hemoCellFields.cpp:676-688)
+            drop = np.nonzero((ext[:, 2] == 0) & ~refreshed)[0].astype(np.int32)
+            if len(drop):
+                e.remove_cells(t, drop)
+                self.stats["cells_dropped"] += len(drop)
+
+    def _dev(self):
+        return getattr(self.e, "device", "cpu")
+
+    # ------------------------------------------------------------------ HemoCell::iterate on a slab
+    def prepare(self):
+        self.halo_exchange_begin(2)()
+        self.halo_fresh = True
+
+    def step(self):
+        e = self.e
+        it = self.iter
+        e.spread()                                            # core/hemoCell.cpp:313
+        if self.halo_fresh:
+            e.collide(0)                                      # :317
+        else:
+            finish = self.halo_exchange_begin(1)
+            if self.overlap:
+                e.collide(1)                                  # interior planes while the faces are in flight
+                finish()
+                e.collide(2)
+            else:
+                finish()
+                e.collide(0)
+        e.step_end()
+        self.halo_fresh = False
+        if it % self.k_p == 0:                                # :327-332
+            self.halo_exchange_begin(2)()                     # full planes: velocities are interpolated at halo nodes too
+            self.halo_fresh = True
+            e.interpolate()
+            self.sync_cells()
+        e.advance()                                           # :342
+        e.mechanics(it)                                       # :345
+        self.iter = it + 1
+
+    def run(self, n):
+        for _ in range(n):
+            self.step()
+
+
+class SlabExchange:
+    """binds a SlabRunner to the HIP engine and torch.distributed"""
+
+    def __init__(self, runner, comm=None):
+        self.runner = runner
+        dev = torch.device("cuda", torch.cuda.current_device())
+        # run the library on torch's current stream so that RCCL transfers are ordered with the kernels
+        host.check(host.capi.lib().hc_set_stream(torch.cuda.current_stream().cuda_stream))
+        self.engine = HipEngine(runner.lattice, runner.cells, dev)
+        self.comm = comm or NeighbourComm(runner.rank, runner.world, runner.periodic[0])
+        self.protocol = SlabProtocol(self.engine, self.comm, runner.k_p, runner.nx_global, runner.periodic[0])
+        assert runner.nx >= 40, "a slab must be wider than two cell diameters plus the envelope"
+
+    def load_cells(self, t, centres, angles, min_dist_um=0.0, radius=9.0):
+        """place every cell whose extent touches this slab's extended region; periodic images across the
+        seam are placed with shifted x (core/hemoCellParticleDataTransfer.cpp:33-65)"""
+        r = self.runner
+        x0, x1, nxg = r.x0, r.x0 + r.nx, r.nx_global
+        n = 0
+        for i, (c, a) in enumerate(zip(centres, angles)):
+            for shift in ((0.0, -nxg, nxg) if r.periodic[0] else (0.0,)):
+                cx = c[0] + shift
+                if cx + radius >= x0 - E_SHARE and cx - radius < x1 + E_SHARE:
+                    cc = np.array([cx, c[1], c[2]])
+                    n += bool(r.cells.addCell(t, cc, a, min_dist_um, cell_id=i))
+                    break
+        # exact test on the placed vertices: keep cells that own a vertex here or reach within E_SHARE
+        ext = self.engine.cell_extents(t)
+        keep = (ext[:, 2] > 0) | ((ext[:, 1] >= x0 - E_SHARE) & (ext[:, 0] < x1 + E_SHARE))
+        drop = np.nonzero(~keep)[0].astype(np.int32)
+        if len(drop):
+            self.engine.remove_cells(t, drop)
+        return n - len(drop)
+
+    def owned_vertices(self):
+        return self.engine.owned_vertices()
+
+    def prepare(self):
+        self.protocol.prepare()
+
+    def run(self, n):
+        self.protocol.run(n)

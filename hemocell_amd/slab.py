@@ -67,3 +67,24 @@ class SlabRunner:
             self.hemocell.iterate(n)
         else:
             self.exchange.run(n)
+
+    # ---- inspection helpers (tests / output): gather-free, per rank
+    def populations(self):
+        """post-stream populations of this slab; the view pulls from the halo planes, so refresh them first"""
+        if self.exchange is not None:
+            self.exchange.protocol.halo_exchange_begin(2)()
+        return self.lattice.populations()
+
+    def owned_vertex_table(self, t=0):
+        """(cell id, vertex id, position) of the vertices whose nearest node lies in this slab"""
+        pos = self.cells.positions
+        ids = self.cells.cell_ids()
+        f, n = self.cells.type_range(t)
+        nv = self.cells.types[t].nv
+        p = pos[f:f + n * nv].reshape(n, nv, 3)
+        first = sum(self.cells.type_range(u)[1] for u in range(t))
+        cid = ids[first:first + n]
+        g = np.floor(p[:, :, 0] + 0.5).astype(np.int64) - self.x0
+        own = (g >= 0) & (g < self.nx)
+        ci, vi = np.nonzero(own)
+        return cid[ci], vi, p[ci, vi]

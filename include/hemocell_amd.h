@@ -161,6 +161,23 @@ int hcp_mechanics_components(hc_cells *C, int type, double *comp);
  * setParticleVelocityUpdateTimeScaleSeparation. iter is read and advanced. */
 int hc_iterate(hc_lattice *L, hc_cells *C, long *iter, int n, int particle_timescale, int force_limit,
                int deletion_check_every);
+/* ---- multi-slab particle envelopes: HemoCellFields::syncEnvelopes (core/hemoCellFields.cpp:377-499) and
+ * HemoCellParticleDataTransfer::send/receive (core/hemoCellParticleDataTransfer.cpp:33-180).  The host
+ * decides WHICH cells cross a slab face (from hcp_cell_extents); the records move device-to-device.
+ * A record is 9 doubles per vertex: position, velocity, force (the mutable part of serializeValues_t,
+ * core/hemoCellParticle.h:45-63); x_shift is the periodic offset (+-nx_global) of :33-65. */
+int hcp_cell_extents(hc_cells *C, int type, double *ext /*[n_cells][3] = min x, max x, #vertices whose nearest node is in this slab*/);
+size_t hcp_record_doubles(const hc_cells *C, int type); /* doubles per cell record */
+int hcp_pack_cells(hc_cells *C, int type, const int *slots, int n, double x_shift, double *dev_buf);
+/* merge rule of HemoCellParticleField::addParticle (core/hemoCellParticleField.cpp:173-235): a local vertex
+ * (nearest node in this slab) is kept, any other is overwritten; is_new cells are appended (slots must be
+ * n_cells, n_cells+1, ... in order) */
+int hcp_unpack_cells(hc_cells *C, int type, const int *slots, const long *cell_ids, const int *is_new, int n,
+                     const double *dev_buf);
+/* deleteNonLocalParticles (core/hemoCellFields.cpp:676-688) at cell granularity; holes are filled from the tail */
+int hcp_remove_cells(hc_cells *C, int type, const int *slots, int n);
+int hcp_owned_vertices(hc_cells *C, long *n_owned); /* vertices whose nearest node lies in this slab */
+
 /* CellInformationFunctionals (helper/cellInfo.cpp:39-80,140-180): per cell volume, area, bbox[6], centroid[3] */
 int hcp_cell_info(hc_cells *C, int type, double *volume, double *area, double *bbox, double *centroid);
 

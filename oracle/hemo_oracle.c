@@ -727,7 +727,10 @@ void orc_cell_forces(const orc_celltype *T, const double *pos, const double *vel
 int orc_phi2_stencil(const orc_lattice *L, const double pos[3], long nodes[8], double weights[8]) {
   const int dims[3] = {L->nx, L->ny, L->nz};
   long center[3];
-  for (int d = 0; d < 3; d++) center[d] = (long)(pos[d] + 0.5);
+  /* plint(position+0.5) (:86) truncates; it equals floor on the block-relative coordinates (>= 0) the
+   * reference applies it to.  floor is used so that an unwrapped periodic image at negative x picks the
+   * nodes of its wrapped position. */
+  for (int d = 0; d < 3; d++) center[d] = (long)floor(pos[d] + 0.5);
   int cnt = 0; double total = 0;
   for (int dx = -1; dx < 2; dx++)
     for (int dy = -1; dy < 2; dy++)
@@ -827,7 +830,7 @@ int orc_sim_add_cell(orc_sim *S, int type, const double centre_lu[3], const doub
   int ok = 1;
   for (long i = 0; i < nv && ok; i++) {
     double v[3] = {centre_lu[0] + m[3 * i], centre_lu[1] + m[3 * i + 1], centre_lu[2] + m[3 * i + 2]};
-    long n[3] = {(int)(v[0] + 0.5), (int)(v[1] + 0.5), (int)(v[2] + 0.5)};
+    long n[3] = {(long)floor(v[0] + 0.5), (long)floor(v[1] + 0.5), (long)floor(v[2] + 0.5)}; /* int(vertex+0.5), :135 */
     int inside;
     if (node_is_boundary_abs(S->L, n[0], n[1], n[2], &inside)) { ok = 0; break; }
     for (int px = -deny; px <= deny && ok; px++) for (int py = -deny; py <= deny && ok; py++) for (int pz = -deny; pz <= deny; pz++)
@@ -913,7 +916,7 @@ void orc_sim_advance(orc_sim *S) {
       int tagged = 0;
       for (long i = 0; i < nv && !tagged; i++) {
         const double *x = S->particles[off + i].position;
-        long nx = (long)(x[0] + 0.5), ny = (long)(x[1] + 0.5), nz = (long)(x[2] + 0.5);
+        long nx = (long)floor(x[0] + 0.5), ny = (long)floor(x[1] + 0.5), nz = (long)floor(x[2] + 0.5);
         int inside;
         if (node_is_boundary_abs(S->L, nx, ny, nz, &inside)) tagged = 1;
       }

@@ -1,0 +1,75 @@
+"""two ranks (two processes sharing the one GPU of the test box, gloo transport) vs one rank: the slab
+decomposition with halo exchange and particle envelopes must reproduce the single-domain run."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+NXG, NY, NZ = 96, 34, 34
+CELLS = [((10.0, 16.5, 16.5), (90, 0, 0)), ((46.5, 16.0, 17.0), (80, 20, 10)), ((93.0, 17.0, 16.0), (90, 0, 30)),
+         ((70.0, 12.0, 20.0), (10, 20, 30))]
+STEPS, K_P, K_M = 60, 2, 4
+FORCE = (2e-5, 0.0, 0.0)
+
+
+def _build(rank, world):
+    from hemocell_amd import host
+    from hemocell_amd.slab import SlabRunner
+    P = host.base_parameters()
+    r = SlabRunner(NXG // world, NY, NZ, rank, world, P, periodic=(True, False, False), particle_timescale=K_P,
+                   material_timescale=K_M, deletion_check_every=1000000)
+    mask, _ = host.pipe_mask(NXG, NY, NZ)
+    r.define_bounce_back(mask)
+    r.lattice.latticeEquilibrium(1.0, (0, 0, 0))
+    r.lattice.setExternalVector(FORCE)
+    r.add_cell_type(host.CellType.rbc(P))
+    r.load_cells(0, [np.array(c) for c, _ in CELLS], [np.array(a) for _, a in CELLS])
+    r.prepare()
+    return r, mask
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from hemocell_amd import host
+    host.init(0)
+    r, _ = _build(rank, world)
+    r.run(STEPS)
+    cid, vid, pos = r.owned_vertex_table(0)
+    torch.save(dict(f=r.populations(), cid=cid, vid=vid, pos=pos, held=r.cells.counts()[1], stats=r.exchange.protocol.stats),
+               os.path.join(out, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_slabs_match_single_domain(tmp_path, gpu):
+    import torch.multiprocessing as mp
+    world = 2
+    port = 29500 + os.getpid() % 400
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, "r%d.pt" % k), weights_only=False) for k in range(world)]
+    ref, mask = _build(0, 1)
+    ref.run(STEPS)
+    f_ref = ref.lattice.populations().reshape(NXG, NY * NZ, 19)
+    f_two = np.concatenate([r["f"].reshape(NXG // world, NY * NZ, 19) for r in res], axis=0)
+    fluid = (mask.reshape(NXG, NY * NZ) == 0)
+    err_f = np.abs(f_two - f_ref)[fluid].max()
+    assert err_f <= 1e-12, err_f
+    p_ref = ref.cells.positions.reshape(len(CELLS), -1, 3)
+    seen = np.zeros(p_ref.shape[:2], dtype=int)
+    for r in res:
+        for c, v, p in zip(r["cid"], r["vid"], r["pos"]):
+            d = p - p_ref[c, v]
+            d[0] = (d[0] + NXG / 2) % NXG - NXG / 2
+            assert np.abs(d).max() <= 1e-10, (c, v, d)
+            seen[c, v] += 1
+    assert (seen == 1).all()          # every vertex owned by exactly one rank
+    assert sum(r["held"] for r in res) > len(CELLS)   # cells near the faces are replicated

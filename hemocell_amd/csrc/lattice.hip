@@ -404,6 +404,16 @@ int hcl_collide_stream_part(hc_lattice *L, int part) {
   if (part == 0) rc = launch_collide(L, 0, L->nx);
   else if (part == 1) rc = launch_collide(L, 1, L->nx - 2);
   else { rc = launch_collide(L, 0, 1); if (rc == HC_OK) rc = launch_collide(L, L->nx - 1, 1); }
+  if (rc == HC_OK && L->n_slabs > 1 && part != 1) {
+    // the kernel zeroes the other-parity IBM force on the bulk planes; envelope copies of cells also
+    // spread onto the halo planes, which have to be cleared as well
+    double *Fz = L->force[1 - L->fcur];
+    const size_t hb = (size_t)HALO * L->plane * sizeof(double);
+    for (int d = 0; d < 3; d++) {
+      HC_HIP(hipMemsetAsync(Fz + (size_t)d * L->npad, 0, hb, hc::stream()));
+      HC_HIP(hipMemsetAsync(Fz + (size_t)d * L->npad + (size_t)(HALO + L->nx) * L->plane, 0, hb, hc::stream()));
+    }
+  }
   return rc;
 }
 

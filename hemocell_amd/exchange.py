@@ -296,8 +296,12 @@ class SlabExchange:
     def __init__(self, runner, comm=None):
         self.runner = runner
         dev = torch.device("cuda", torch.cuda.current_device())
-        # run the library on torch's current stream so that RCCL transfers are ordered with the kernels
-        host.check(host.capi.lib().hc_set_stream(torch.cuda.current_stream().cuda_stream))
+        # kernels of the library and torch's copies / RCCL transfers must be ordered on ONE stream.  torch's
+        # default stream is the null stream (handle 0, which hc_set_stream reads as "library stream"), so a
+        # dedicated stream is made current for torch and handed to the library.
+        self.stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(self.stream)
+        host.check(host.capi.lib().hc_set_stream(self.stream.cuda_stream))
         self.engine = HipEngine(runner.lattice, runner.cells, dev)
         self.comm = comm or NeighbourComm(runner.rank, runner.world, runner.periodic[0])
         self.protocol = SlabProtocol(self.engine, self.comm, runner.k_p, runner.nx_global, runner.periodic[0])

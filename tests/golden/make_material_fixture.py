@@ -20,7 +20,7 @@ def main():
     rng = np.random.default_rng(20260404)
     cases = []
     for l_eq in (0.5e-6, 0.35e-6):
-        for amp in (0.0, 0.02, 0.1, 0.25):
+        for amp in (0.0, 0.01, 0.03, 0.06):
             model = Cell(l_eq)
             nodes = model.mesh.nodes
             for n in nodes:

@@ -222,6 +222,172 @@ __global__ __launch_bounds__(256) void ibm_interpolate_kernel(LatView v, PopView
   vx[i] = a0; vy[i] = a1; vz[i] = a2;
 }
 
+
+// ----------------------------------------------------------------------------
+// LDS-tiled IBM kernels: one workgroup per cell.
+//
+// All 8-node stencils of a cell fall into the cell's bounding box (+1).  Spread: the workgroup
+// accumulates one force component at a time on an LDS tile of that box (ds_add_f64), then flushes only the
+// touched nodes to HBM with one fp64 atomic each, z-contiguous -- several times fewer, better shaped
+// global atomics than one per (vertex, node, component).  Interpolate: the nodes the cell touches are
+// compacted, the node velocity (19-population gather + moments) is evaluated once per node into LDS, and
+// every vertex then blends its 8 values from LDS.
+constexpr int TILE_CAP = 6144;       // nodes per tile (18 x 18 x 18 = 5832 fits)
+constexpr int NODE_CAP = 2048;       // distinct nodes of one cell for the interpolation
+
+struct Tile { int o[3]; int e[3]; int vol; };
+
+__device__ __forceinline__ int stencil_base(const LatView &v, double px, double py, double pz, int b[3]) {
+  const double p[3] = {px, py, pz};
+#pragma unroll
+  for (int a = 0; a < 3; a++) { const long c = nearest_node(p[a]); b[a] = (int)c + ((p[a] < (double)c) ? -1 : 0); }
+  return 0;
+}
+
+__device__ __forceinline__ void tile_bbox(const LatView &v, int nv, long base, const double *px, const double *py, const double *pz,
+                                          int *s_lo, int *s_hi, Tile &t) {
+  const int tid = threadIdx.x, nth = blockDim.x;
+  if (tid < 3) { s_lo[tid] = 0x7fffffff; s_hi[tid] = -0x7fffffff; }
+  __syncthreads();
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
+  for (int i = tid; i < nv; i += nth) {
+    int b[3]; stencil_base(v, px[base + i], py[base + i], pz[base + i], b);
+#pragma unroll
+    for (int a = 0; a < 3; a++) { lo[a] = min(lo[a], b[a]); hi[a] = max(hi[a], b[a] + 1); }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) { atomicMin(&s_lo[a], lo[a]); atomicMax(&s_hi[a], hi[a]); }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 3; a++) { t.o[a] = s_lo[a]; t.e[a] = s_hi[a] - s_lo[a] + 1; }
+  const long vol = (long)t.e[0] * t.e[1] * t.e[2];
+  t.vol = vol > 0x7fffffff ? 0x7fffffff : (int)vol;
+}
+
+// global lattice element of tile entry i (only meaningful for entries that were admitted by a stencil)
+__device__ __forceinline__ long tile_node(const LatView &v, const Tile &t, int i, int &lx, int &ly, int &lz) {
+  const int tz = i % t.e[2], ty = (i / t.e[2]) % t.e[1], tx = i / (t.e[2] * t.e[1]);
+  long gx = (long)t.o[0] + tx - v.x0, gy = (long)t.o[1] + ty, gz = (long)t.o[2] + tz;
+  if (v.wrap_x) gx = pmod(gx, v.nx);
+  if (v.per_y) gy = pmod(gy, v.ny);
+  if (v.per_z) gz = pmod(gz, v.nz);
+  lx = (int)gx; ly = (int)gy; lz = (int)gz;
+  return (gx + HALO) * (long)v.plane + gy * v.nz + gz;
+}
+
+__device__ __forceinline__ int tile_index(const Tile &t, const Stencil &s, double px, double py, double pz, const LatView &v) {
+  int b[3]; stencil_base(v, px, py, pz, b);
+  return ((b[0] - t.o[0]) * t.e[1] + (b[1] - t.o[1])) * t.e[2] + (b[2] - t.o[2]);
+}
+
+__global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv, const double *px, const double *py, const double *pz,
+                                                              double *fx, double *fy, double *fz, double *F, int limit_on, double f_limit) {
+  __shared__ double tile[TILE_CAP];
+  __shared__ int s_lo[3], s_hi[3];
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const long base = (long)blockIdx.x * nv;
+  if (limit_on) {  // FORCE_LIMIT cap, core/hemoCellParticleField.cpp:848-852 (mutates sv.force)
+    for (int i = tid; i < nv; i += nth) {
+      const double f0 = fx[base + i], f1 = fy[base + i], f2 = fz[base + i];
+      const double mag = sqrt((f0 * f0 + f1 * f1) + f2 * f2);
+      if (mag > f_limit) { const double sc = f_limit / mag; fx[base + i] = f0 * sc; fy[base + i] = f1 * sc; fz[base + i] = f2 * sc; }
+    }
+  }
+  Tile t;
+  tile_bbox(v, nv, base, px, py, pz, s_lo, s_hi, t);
+  const bool tiled = t.vol <= TILE_CAP;
+  const int sy = t.e[2], sx = t.e[1] * t.e[2];
+  for (int comp = 0; comp < 3; comp++) {
+    const double *fc = comp == 0 ? fx : comp == 1 ? fy : fz;
+    double *Fc = F + (long)comp * v.npad;
+    if (tiled) {
+      for (int i = tid; i < t.vol; i += nth) tile[i] = 0.0;
+      __syncthreads();
+    }
+    for (int i = tid; i < nv; i += nth) {
+      const double x = px[base + i], y = py[base + i], z = pz[base + i];
+      Stencil s;
+      phi2_stencil(v, x, y, z, s);
+      const double f = 0.0 + fc[base + i];   // force_repulsion (0: disabled in scope) + force, :857-859
+      const int b = tiled ? tile_index(t, s, x, y, z, v) : 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        if (s.node[k] < 0) continue;
+        if (tiled) atomicAdd(&tile[b + (k >> 2) * sx + ((k >> 1) & 1) * sy + (k & 1)], f * s.w[k]);
+        else unsafeAtomicAdd(&Fc[s.node[k]], f * s.w[k]);
+      }
+    }
+    if (tiled) {
+      __syncthreads();
+      for (int i = tid; i < t.vol; i += nth) {
+        const double val = tile[i];
+        if (val != 0.0) { int lx, ly, lz; unsafeAtomicAdd(&Fc[tile_node(v, t, i, lx, ly, lz)], val); }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ibm_interpolate_cell_kernel(LatView v, PopView pv, int nv, const double *px, const double *py,
+                                                                   const double *pz, double *vx, double *vy, double *vz) {
+  __shared__ int slot[TILE_CAP];
+  __shared__ int list[NODE_CAP];
+  __shared__ double ux[NODE_CAP], uy[NODE_CAP], uz[NODE_CAP];
+  __shared__ int s_lo[3], s_hi[3], s_count;
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const long base = (long)blockIdx.x * nv;
+  Tile t;
+  tile_bbox(v, nv, base, px, py, pz, s_lo, s_hi, t);
+  bool tiled = t.vol <= TILE_CAP;
+  const int sy = t.e[2], sx = t.e[1] * t.e[2];
+  if (tiled) {
+    for (int i = tid; i < t.vol; i += nth) slot[i] = -1;
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    for (int i = tid; i < nv; i += nth) {   // mark the admitted nodes
+      const double x = px[base + i], y = py[base + i], z = pz[base + i];
+      Stencil s;
+      phi2_stencil(v, x, y, z, s);
+      const int b = tile_index(t, s, x, y, z, v);
+#pragma unroll
+      for (int k = 0; k < 8; k++) if (s.node[k] >= 0) slot[b + (k >> 2) * sx + ((k >> 1) & 1) * sy + (k & 1)] = -2;
+    }
+    __syncthreads();
+    for (int i = tid; i < t.vol; i += nth) {   // compact
+      if (slot[i] == -2) { const int n = atomicAdd(&s_count, 1); slot[i] = n; if (n < NODE_CAP) list[n] = i; }
+    }
+    __syncthreads();
+    if (s_count > NODE_CAP) tiled = false;   // uniform: s_count is shared
+  }
+  if (tiled) {
+    const int n = s_count;
+    for (int k = tid; k < n; k += nth) {       // node velocity once per node
+      int lx, ly, lz;
+      const long node = tile_node(v, t, list[k], lx, ly, lz);
+      double u[3];
+      node_velocity(v, pv, lx, ly, lz, node, u);
+      ux[k] = u[0]; uy[k] = u[1]; uz[k] = u[2];
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < nv; i += nth) {
+    const double x = px[base + i], y = py[base + i], z = pz[base + i];
+    Stencil s;
+    phi2_stencil(v, x, y, z, s);
+    const int b = tiled ? tile_index(t, s, x, y, z, v) : 0;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (s.node[k] < 0) continue;
+      double u[3];
+      if (tiled) { const int q = slot[b + (k >> 2) * sx + ((k >> 1) & 1) * sy + (k & 1)]; u[0] = ux[q]; u[1] = uy[q]; u[2] = uz[q]; }
+      else node_velocity(v, pv, s.lx[k], s.ly[k], s.lz[k], s.node[k], u);
+      a0 += (u[0] * s.w[k]); a1 += (u[1] * s.w[k]); a2 += (u[2] * s.w[k]);
+    }
+    vx[base + i] = a0; vy[base + i] = a1; vz[base + i] = a2;
+  }
+}
+
 // ----------------------------------------------------------------------------
 // advance + boundary tagging
 __global__ __launch_bounds__(256) void advance_kernel(LatView v, long n, double *px, double *py, double *pz, const double *vx,
@@ -607,6 +773,9 @@ std::vector<int> flatten(const std::vector<std::array<long, N>> &v) {
 
 }  // namespace
 
+static int g_ibm_per_vertex = 0;  // 1: one thread per vertex with direct global atomics (kept for A/B and as reference)
+extern "C" int hc_debug_ibm_per_vertex(int on) { g_ibm_per_vertex = on; return HC_OK; }
+
 static int free_device_arrays(hc_cells *C) {
   for (int d = 0; d < 3; d++) {
     if (C->pos[d]) hipFree(C->pos[d]);
@@ -975,9 +1144,15 @@ int hcp_spread(hc_cells *C, int force_limit) {
   for (int t = 0; t < C->ntypes; t++) {
     const long n = C->ncells[t] * C->types[t]->host.nv, f = C->first[t];
     if (n == 0) continue;
-    hipLaunchKernelGGL(ibm_spread_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), v, n,
-                       (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
-                       C->frc[0] + f, C->frc[1] + f, C->frc[2] + f, C->L->force[C->L->fcur], force_limit, C->P.f_limit);
+    const int nv = C->types[t]->host.nv;
+    if (g_ibm_per_vertex)
+      hipLaunchKernelGGL(ibm_spread_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), v, n,
+                         (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
+                         C->frc[0] + f, C->frc[1] + f, C->frc[2] + f, C->L->force[C->L->fcur], force_limit, C->P.f_limit);
+    else
+      hipLaunchKernelGGL(ibm_spread_cell_kernel, dim3((unsigned)C->ncells[t]), dim3(nv > 128 ? 256 : 128), 0, hc::stream(), v, nv,
+                         (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
+                         C->frc[0] + f, C->frc[1] + f, C->frc[2] + f, C->L->force[C->L->fcur], force_limit, C->P.f_limit);
     HC_HIP(hipGetLastError());
   }
   return HC_OK;
@@ -995,9 +1170,15 @@ int hcp_interpolate(hc_cells *C) {
   for (int t = 0; t < C->ntypes; t++) {
     const long n = C->ncells[t] * C->types[t]->host.nv, f = C->first[t];
     if (n == 0) continue;
-    hipLaunchKernelGGL(ibm_interpolate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), v, pv, n,
-                       (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
-                       C->vel[0] + f, C->vel[1] + f, C->vel[2] + f);
+    const int nv = C->types[t]->host.nv;
+    if (g_ibm_per_vertex)
+      hipLaunchKernelGGL(ibm_interpolate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), v, pv, n,
+                         (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
+                         C->vel[0] + f, C->vel[1] + f, C->vel[2] + f);
+    else
+      hipLaunchKernelGGL(ibm_interpolate_cell_kernel, dim3((unsigned)C->ncells[t]), dim3(nv > 128 ? 256 : 128), 0, hc::stream(), v, pv, nv,
+                         (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
+                         C->vel[0] + f, C->vel[1] + f, C->vel[2] + f);
     HC_HIP(hipGetLastError());
   }
   return HC_OK;

@@ -49,6 +49,8 @@ int hc_synchronize(void);
 int hc_profile_enable(int on);
 int hc_profile_read(const char *kernel, double *total_ms, long *launches); /* "collide_stream", "ibm_spread", "ibm_interpolate", "advance", "mechanics" */
 int hc_profile_reset(void);
+/* A/B switch: 1 = per-vertex IBM kernels with direct global atomics instead of the LDS-tiled per-cell kernels */
+int hc_debug_ibm_per_vertex(int on);
 
 /* ------------------------------------------------------------------ lattice */
 /* MultiBlockLattice3D<T,DESCRIPTOR>(nx,ny,nz, new GuoExternalForceBGKdynamics(omega))

@@ -163,10 +163,12 @@ __global__ __launch_bounds__(256) void collide_stream_kernel(LatArgs a) {
   const int x = a.x_begin + blockIdx.y;
   const int y = p / a.nz, z = p - y * a.nz;
   const long node = (long)(x + HALO) * a.plane + p;
+  const uint8_t m = a.mask[node];
+  if (m == 2) return;   // solid node with no fluid neighbour: inert under full-way bounce-back
   const Nbr n = neighbours(a, x, y, z);
   double f[HC_Q];
   pull(a.fin, a.npad, node, n, f);
-  const bool wall = a.mask[node] != 0;
+  const bool wall = m != 0;
   if (wall) {
     // BounceBack::collide: swap opposite pairs (full-way bounce-back)
 #pragma unroll
@@ -373,7 +375,32 @@ int hcl_dims(const hc_lattice *L, int dims[3]) {
 int hcl_set_mask(hc_lattice *L, const uint8_t *mask_with_halo) {
   HC_REQUIRE(L && mask_with_halo, "hcl_set_mask: null pointer");
   L->hmask.assign(mask_with_halo, mask_with_halo + L->npad);
-  HC_HIP(hipMemcpyAsync(L->mask, mask_with_halo, L->npad, hipMemcpyHostToDevice, hc::stream()));
+  for (auto &m : L->hmask) m = m ? 1 : 0;
+  // class 2 = solid node without any fluid neighbour.  Full-way bounce-back returns every population to
+  // where it came from, so such a node never exchanges anything with the fluid: the collide kernel skips
+  // it (no loads, no stores).  Results on fluid nodes are unchanged, bit for bit.
+  {
+    static const int cx[HC_Q] = HC_CX, cy[HC_Q] = HC_CY, cz[HC_Q] = HC_CZ;
+    const int NX = L->nx + 2 * HALO, ny = L->ny, nz = L->nz;
+    std::vector<uint8_t> cls(L->hmask);
+    for (int x = 0; x < NX; x++)
+      for (int y = 0; y < ny; y++)
+        for (int z = 0; z < nz; z++) {
+          const size_t k = ((size_t)x * ny + y) * nz + z;
+          if (!L->hmask[k]) continue;
+          bool fluid_near = false;
+          for (int q = 1; q < HC_Q && !fluid_near; q++) {
+            int xx = x + cx[q], yy = y + cy[q], zz = z + cz[q];
+            if (xx < 0 || xx >= NX) { fluid_near = true; break; }   // beyond the halo: unknown, keep the node active
+            if (yy < 0 || yy >= ny) { if (L->periodic[1]) yy = (yy + ny) % ny; else continue; }
+            if (zz < 0 || zz >= nz) { if (L->periodic[2]) zz = (zz + nz) % nz; else continue; }
+            if (!L->hmask[((size_t)xx * ny + yy) * nz + zz]) fluid_near = true;
+          }
+          if (!fluid_near) cls[k] = 2;
+        }
+    L->hmask.swap(cls);
+  }
+  HC_HIP(hipMemcpyAsync(L->mask, L->hmask.data(), L->npad, hipMemcpyHostToDevice, hc::stream()));
   HC_HIP(hipStreamSynchronize(hc::stream()));
   return HC_OK;
 }

@@ -280,78 +280,175 @@ __device__ __forceinline__ int tile_index(const Tile &t, const Stencil &s, doubl
   return ((b[0] - t.o[0]) * t.e[1] + (b[1] - t.o[1])) * t.e[2] + (b[2] - t.o[2]);
 }
 
+// compact per-vertex stencil kept in registers across the passes of the cell kernels
+struct VStencil { double w[8]; int base; unsigned adm; };   // base = tile index of the lowest corner; adm = admitted-node bits
+
+constexpr int NVPT = 3;        // vertices per thread held in registers (642 vertices / 256 threads)
+constexpr int MAXW = 4;        // waves per workgroup
+
+// bounding box of all stencil nodes of the cell: per-thread min/max -> wave shuffles -> LDS -> everyone
+__device__ __forceinline__ void block_bbox(int lo[3], int hi[3], int *s_red, Tile &t) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { lo[a] = min(lo[a], __shfl_xor(lo[a], off)); hi[a] = max(hi[a], __shfl_xor(hi[a], off)); }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) { s_red[(tid >> 6) * 6 + a] = lo[a]; s_red[(tid >> 6) * 6 + 3 + a] = hi[a]; }
+  }
+  __syncthreads();
+  const int nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    int l = s_red[a], h = s_red[3 + a];
+    for (int w = 1; w < nw; w++) { l = min(l, s_red[w * 6 + a]); h = max(h, s_red[w * 6 + 3 + a]); }
+    t.o[a] = l; t.e[a] = h - l + 1;
+  }
+  const long vol = (long)t.e[0] * t.e[1] * t.e[2];
+  t.vol = vol > 0x7fffffff ? 0x7fffffff : (int)vol;
+}
+
+// mask class of tile entry i: 0 fluid, 1/2 boundary, 3 not addressable (outside the domain / halo range)
+__device__ __forceinline__ unsigned char tile_mask(const LatView &v, const Tile &t, int i) {
+  const int tz = i % t.e[2], ty = (i / t.e[2]) % t.e[1], tx = i / (t.e[2] * t.e[1]);
+  long lx = (long)t.o[0] + tx - v.x0, gy = (long)t.o[1] + ty, gz = (long)t.o[2] + tz;
+  if (v.wrap_x) lx = pmod(lx, v.nx);
+  else if (v.halo_x) { if (lx < -HALO || lx >= v.nx + HALO) return 3; }
+  else if (lx < 0 || lx >= v.nx) return 3;
+  if (gy < 0 || gy >= v.ny) { if (v.per_y) gy = pmod(gy, v.ny); else return 3; }
+  if (gz < 0 || gz >= v.nz) { if (v.per_z) gz = pmod(gz, v.nz); else return 3; }
+  return v.mask[(lx + HALO) * (long)v.plane + gy * v.nz + gz];
+}
+
+// interpolationCoefficientsPhi2 against the LDS copy of the mask; same arithmetic and visiting order as phi2_stencil
+__device__ __forceinline__ void tile_stencil(const Tile &t, const unsigned char *mt, double px, double py, double pz, const int b[3], VStencil &o) {
+  const int sy = t.e[2], sx = t.e[1] * t.e[2];
+  o.base = ((b[0] - t.o[0]) * t.e[1] + (b[1] - t.o[1])) * t.e[2] + (b[2] - t.o[2]);
+  o.adm = 0;
+  double total = 0.0;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int idx = i * 4 + j * 2 + k;
+        const double weight = phi2(px - (double)(b[0] + i)) * phi2(py - (double)(b[1] + j)) * phi2(pz - (double)(b[2] + k));
+        const bool adm = (weight != 0.0) && (mt[o.base + i * sx + j * sy + k] == 0);
+        if (adm) { total += weight; o.adm |= 1u << idx; }
+        o.w[idx] = adm ? weight : 0.0;
+      }
+  const double coeff = 1.0 / total;
+#pragma unroll
+  for (int idx = 0; idx < 8; idx++) o.w[idx] *= coeff;
+}
+
+// shared prologue of the two cell kernels: positions -> registers, tile, mask tile, stencils.
+// returns false (uniformly) when the cell does not fit the tile and the caller must take the fallback path
+__device__ __forceinline__ bool cell_prologue(const LatView &v, int nv, long base, const double *px, const double *py, const double *pz,
+                                              int *s_red, unsigned char *mt, Tile &t, VStencil vs[NVPT]) {
+  const int tid = threadIdx.x, nth = blockDim.x;
+  double p[NVPT][3]; int b[NVPT][3];
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
+#pragma unroll
+  for (int j = 0; j < NVPT; j++) {
+    const int i = tid + j * nth;
+    if (i < nv) {
+      p[j][0] = px[base + i]; p[j][1] = py[base + i]; p[j][2] = pz[base + i];
+      stencil_base(v, p[j][0], p[j][1], p[j][2], b[j]);
+#pragma unroll
+      for (int a = 0; a < 3; a++) { lo[a] = min(lo[a], b[j][a]); hi[a] = max(hi[a], b[j][a] + 1); }
+    }
+  }
+  block_bbox(lo, hi, s_red, t);
+  if (t.vol > TILE_CAP || nv > NVPT * nth) return false;
+  for (int i = tid; i < t.vol; i += nth) mt[i] = tile_mask(v, t, i);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NVPT; j++) {
+    vs[j].adm = 0;
+    if (tid + j * nth < nv) tile_stencil(t, mt, p[j][0], p[j][1], p[j][2], b[j], vs[j]);
+  }
+  return true;
+}
+
 __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv, const double *px, const double *py, const double *pz,
-                                                              double *fx, double *fy, double *fz, double *F, int limit_on, double f_limit) {
+                                                              double *fx, double *fy, double *fz, double *F, int limit_on, double f_limit, int dbg) {
   __shared__ double tile[TILE_CAP];
-  __shared__ int s_lo[3], s_hi[3];
+  __shared__ unsigned char mt[TILE_CAP];
+  __shared__ int s_red[6 * MAXW];
   const int tid = threadIdx.x, nth = blockDim.x;
   const long base = (long)blockIdx.x * nv;
-  if (limit_on) {  // FORCE_LIMIT cap, core/hemoCellParticleField.cpp:848-852 (mutates sv.force)
+  // FORCE_LIMIT cap, core/hemoCellParticleField.cpp:848-852 (mutates sv.force)
+  if (limit_on) {
     for (int i = tid; i < nv; i += nth) {
       const double f0 = fx[base + i], f1 = fy[base + i], f2 = fz[base + i];
       const double mag = sqrt((f0 * f0 + f1 * f1) + f2 * f2);
       if (mag > f_limit) { const double sc = f_limit / mag; fx[base + i] = f0 * sc; fy[base + i] = f1 * sc; fz[base + i] = f2 * sc; }
     }
   }
-  Tile t;
-  tile_bbox(v, nv, base, px, py, pz, s_lo, s_hi, t);
-  const bool tiled = t.vol <= TILE_CAP;
+  Tile t; VStencil vs[NVPT];
+  if (!cell_prologue(v, nv, base, px, py, pz, s_red, mt, t, vs)) {
+    // cell larger than the tile (or mesh larger than the register budget): direct global atomics
+    for (int i = tid; i < nv; i += nth) {
+      Stencil s;
+      phi2_stencil(v, px[base + i], py[base + i], pz[base + i], s);
+      const double f0 = 0.0 + fx[base + i], f1 = 0.0 + fy[base + i], f2 = 0.0 + fz[base + i];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        if (s.node[k] < 0) continue;
+        unsafeAtomicAdd(&F[s.node[k]], f0 * s.w[k]);
+        unsafeAtomicAdd(&F[v.npad + s.node[k]], f1 * s.w[k]);
+        unsafeAtomicAdd(&F[2 * v.npad + s.node[k]], f2 * s.w[k]);
+      }
+    }
+    return;
+  }
   const int sy = t.e[2], sx = t.e[1] * t.e[2];
   for (int comp = 0; comp < 3; comp++) {
     const double *fc = comp == 0 ? fx : comp == 1 ? fy : fz;
     double *Fc = F + (long)comp * v.npad;
-    if (tiled) {
-      for (int i = tid; i < t.vol; i += nth) tile[i] = 0.0;
-      __syncthreads();
-    }
-    for (int i = tid; i < nv; i += nth) {
-      const double x = px[base + i], y = py[base + i], z = pz[base + i];
-      Stencil s;
-      phi2_stencil(v, x, y, z, s);
-      const double f = 0.0 + fc[base + i];   // force_repulsion (0: disabled in scope) + force, :857-859
-      const int b = tiled ? tile_index(t, s, x, y, z, v) : 0;
+    for (int i = tid; i < t.vol; i += nth) tile[i] = 0.0;
+    __syncthreads();
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        if (s.node[k] < 0) continue;
-        if (tiled) atomicAdd(&tile[b + (k >> 2) * sx + ((k >> 1) & 1) * sy + (k & 1)], f * s.w[k]);
-        else unsafeAtomicAdd(&Fc[s.node[k]], f * s.w[k]);
-      }
+    for (int j = 0; j < NVPT; j++) {
+      const int i = tid + j * nth;
+      if (i >= nv) continue;
+      const double f = 0.0 + fc[base + i];   // force_repulsion (0: disabled in scope) + force, :857-859
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (vs[j].adm & (1u << k)) atomicAdd(&tile[vs[j].base + (k >> 2) * sx + ((k >> 1) & 1) * sy + (k & 1)], f * vs[j].w[k]);
     }
-    if (tiled) {
-      __syncthreads();
-      for (int i = tid; i < t.vol; i += nth) {
-        const double val = tile[i];
-        if (val != 0.0) { int lx, ly, lz; unsafeAtomicAdd(&Fc[tile_node(v, t, i, lx, ly, lz)], val); }
-      }
-      __syncthreads();
+    __syncthreads();
+    for (int i = tid; i < t.vol; i += nth) {
+      const double val = tile[i];
+      if (val != 0.0 && !(dbg & 2)) { int lx, ly, lz; unsafeAtomicAdd(&Fc[tile_node(v, t, i, lx, ly, lz)], val); }
     }
+    __syncthreads();
   }
 }
 
 __global__ __launch_bounds__(256) void ibm_interpolate_cell_kernel(LatView v, PopView pv, int nv, const double *px, const double *py,
                                                                    const double *pz, double *vx, double *vy, double *vz) {
   __shared__ int slot[TILE_CAP];
+  __shared__ unsigned char mt[TILE_CAP];
   __shared__ int list[NODE_CAP];
   __shared__ double ux[NODE_CAP], uy[NODE_CAP], uz[NODE_CAP];
-  __shared__ int s_lo[3], s_hi[3], s_count;
+  __shared__ int s_red[6 * MAXW], s_count;
   const int tid = threadIdx.x, nth = blockDim.x;
   const long base = (long)blockIdx.x * nv;
-  Tile t;
-  tile_bbox(v, nv, base, px, py, pz, s_lo, s_hi, t);
-  bool tiled = t.vol <= TILE_CAP;
+  Tile t; VStencil vs[NVPT];
+  bool tiled = cell_prologue(v, nv, base, px, py, pz, s_red, mt, t, vs);
   const int sy = t.e[2], sx = t.e[1] * t.e[2];
   if (tiled) {
     for (int i = tid; i < t.vol; i += nth) slot[i] = -1;
     if (tid == 0) s_count = 0;
     __syncthreads();
-    for (int i = tid; i < nv; i += nth) {   // mark the admitted nodes
-      const double x = px[base + i], y = py[base + i], z = pz[base + i];
-      Stencil s;
-      phi2_stencil(v, x, y, z, s);
-      const int b = tile_index(t, s, x, y, z, v);
 #pragma unroll
-      for (int k = 0; k < 8; k++) if (s.node[k] >= 0) slot[b + (k >> 2) * sx + ((k >> 1) & 1) * sy + (k & 1)] = -2;
-    }
+    for (int j = 0; j < NVPT; j++)   // mark the admitted nodes
+#pragma unroll
+      for (int k = 0; k < 8; k++) if (vs[j].adm & (1u << k)) slot[vs[j].base + (k >> 2) * sx + ((k >> 1) & 1) * sy + (k & 1)] = -2;
     __syncthreads();
     for (int i = tid; i < t.vol; i += nth) {   // compact
       if (slot[i] == -2) { const int n = atomicAdd(&s_count, 1); slot[i] = n; if (n < NODE_CAP) list[n] = i; }
@@ -369,19 +466,30 @@ __global__ __launch_bounds__(256) void ibm_interpolate_cell_kernel(LatView v, Po
       ux[k] = u[0]; uy[k] = u[1]; uz[k] = u[2];
     }
     __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NVPT; j++) {
+      const int i = tid + j * nth;
+      if (i >= nv) continue;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        if (!(vs[j].adm & (1u << k))) continue;
+        const int q = slot[vs[j].base + (k >> 2) * sx + ((k >> 1) & 1) * sy + (k & 1)];
+        a0 += (ux[q] * vs[j].w[k]); a1 += (uy[q] * vs[j].w[k]); a2 += (uz[q] * vs[j].w[k]);
+      }
+      vx[base + i] = a0; vy[base + i] = a1; vz[base + i] = a2;
+    }
+    return;
   }
-  for (int i = tid; i < nv; i += nth) {
-    const double x = px[base + i], y = py[base + i], z = pz[base + i];
+  for (int i = tid; i < nv; i += nth) {   // fallback: per-vertex gathers
     Stencil s;
-    phi2_stencil(v, x, y, z, s);
-    const int b = tiled ? tile_index(t, s, x, y, z, v) : 0;
+    phi2_stencil(v, px[base + i], py[base + i], pz[base + i], s);
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       if (s.node[k] < 0) continue;
       double u[3];
-      if (tiled) { const int q = slot[b + (k >> 2) * sx + ((k >> 1) & 1) * sy + (k & 1)]; u[0] = ux[q]; u[1] = uy[q]; u[2] = uz[q]; }
-      else node_velocity(v, pv, s.lx[k], s.ly[k], s.lz[k], s.node[k], u);
+      node_velocity(v, pv, s.lx[k], s.ly[k], s.lz[k], s.node[k], u);
       a0 += (u[0] * s.w[k]); a1 += (u[1] * s.w[k]); a2 += (u[2] * s.w[k]);
     }
     vx[base + i] = a0; vy[base + i] = a1; vz[base + i] = a2;
@@ -773,6 +881,8 @@ std::vector<int> flatten(const std::vector<std::array<long, N>> &v) {
 
 }  // namespace
 
+static int g_dbg_spread = 0;   // timing experiments only: 1 = non-atomic flush (WRONG results), 2 = no flush
+extern "C" int hc_debug_spread_mode(int m) { g_dbg_spread = m; return HC_OK; }
 static int g_ibm_per_vertex = 0;  // 1: one thread per vertex with direct global atomics (kept for A/B and as reference)
 extern "C" int hc_debug_ibm_per_vertex(int on) { g_ibm_per_vertex = on; return HC_OK; }
 
@@ -1152,7 +1262,7 @@ int hcp_spread(hc_cells *C, int force_limit) {
     else
       hipLaunchKernelGGL(ibm_spread_cell_kernel, dim3((unsigned)C->ncells[t]), dim3(nv > 128 ? 256 : 128), 0, hc::stream(), v, nv,
                          (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
-                         C->frc[0] + f, C->frc[1] + f, C->frc[2] + f, C->L->force[C->L->fcur], force_limit, C->P.f_limit);
+                         C->frc[0] + f, C->frc[1] + f, C->frc[2] + f, C->L->force[C->L->fcur], force_limit, C->P.f_limit, g_dbg_spread);
     HC_HIP(hipGetLastError());
   }
   return HC_OK;

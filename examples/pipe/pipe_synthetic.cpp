@@ -1,0 +1,68 @@
+// Synthetic pipe flow driven through the source-level facade: the structure of a HemoCell pipeflow case
+// (warm-up, iterate + re-applied driving force, periodic statistics) on an analytic cylinder instead of a
+// voxelised STL.  Prints "STAT iter cells viscosity mean_force_pN" lines that the caller checks against the
+// reference's validation bounds (tests/validation/pipeflow/test_pipeflow.cpp:87-106).
+#define HEMOCELL_COMPAT_MAIN
+#include "hemocell.h"
+#include "cellInfo.h"
+#include "fluidInfo.h"
+#include "particleInfo.h"
+#include "pltSimpleModel.h"
+#include "rbcHighOrderModel.h"
+#include "writeCellInfoCSV.h"
+
+using namespace hemo;
+
+int main(int argc, char *argv[]) {
+  if (argc < 2) { cout << "Usage: " << argv[0] << " <configuration.xml>" << endl; return -1; }
+  HemoCell hemocell(argv[1], argc, argv);
+  Config *cfg = hemocell.cfg;
+
+  const plint ny = (*cfg)["domain"]["refDirN"].read<int>() + 2, nz = ny, nx = (*cfg)["domain"]["lengthN"].read<int>();
+  std::unique_ptr<MultiScalarField3D<int>> flagMatrix;
+  std::unique_ptr<VoxelizedDomain3D<T>> voxelizedDomain;
+  getFlagMatrixCylinder(nx, ny, nz, voxelizedDomain, flagMatrix);
+  param::lbm_pipe_parameters(*cfg, flagMatrix.get());
+  param::printParameters();
+
+  hemocell.lattice = new MultiBlockLattice3D<T, DESCRIPTOR>(
+      voxelizedDomain->getMultiBlockManagement(), defaultMultiBlockPolicy3D().getBlockCommunicator(),
+      defaultMultiBlockPolicy3D().getCombinedStatistics(), defaultMultiBlockPolicy3D().getMultiCellAccess<T, DESCRIPTOR>(),
+      new GuoExternalForceBGKdynamics<T, DESCRIPTOR>(1.0 / param::tau));
+  defineDynamics(*hemocell.lattice, *flagMatrix, hemocell.lattice->getBoundingBox(), new BounceBack<T, DESCRIPTOR>(1.), 0);
+  hemocell.lattice->toggleInternalStatistics(false);
+  hemocell.lattice->periodicity().toggleAll(false);
+  hemocell.latticeEquilibrium(1., plb::Array<T, 3>(0., 0., 0.));
+  const T drivingForce = 8 * param::nu_lbm * (param::u_lbm_max * 0.5) / param::pipe_radius / param::pipe_radius;
+  hemocell.lattice->initialize();
+
+  hemocell.initializeCellfield();
+  hemocell.addCellType<RbcHighOrderModel>("RBC", RBC_FROM_SPHERE);
+  hemocell.setMaterialTimeScaleSeparation("RBC", (*cfg)["ibm"]["stepMaterialEvery"].read<int>());
+  hemocell.setInitialMinimumDistanceFromSolid("RBC", 0.5);
+  hemocell.addCellType<PltSimpleModel>("PLT", ELLIPSOID_FROM_SPHERE);
+  hemocell.setMaterialTimeScaleSeparation("PLT", (*cfg)["ibm"]["stepMaterialEvery"].read<int>());
+  hemocell.setParticleVelocityUpdateTimeScaleSeparation((*cfg)["ibm"]["stepParticleEvery"].read<int>());
+  hemocell.setSystemPeriodicity(0, true);
+  hemocell.loadParticles();
+
+  setExternalVector(*hemocell.lattice, hemocell.lattice->getBoundingBox(), DESCRIPTOR<T>::ExternalField::forceBeginsAt,
+                    plb::Array<T, DESCRIPTOR<T>::d>(drivingForce, 0.0, 0.0));
+  for (plint i = 0; i < (*cfg)["parameters"]["warmup"].read<plint>(); ++i) hemocell.lattice->collideAndStream();
+
+  const unsigned tmax = (*cfg)["sim"]["tmax"].read<unsigned int>(), tmeas = (*cfg)["sim"]["tmeas"].read<unsigned int>();
+  while (hemocell.iter < tmax) {
+    hemocell.iterate();
+    setExternalVector(*hemocell.lattice, hemocell.lattice->getBoundingBox(), DESCRIPTOR<T>::ExternalField::forceBeginsAt,
+                      plb::Array<T, DESCRIPTOR<T>::d>(drivingForce, 0.0, 0.0));
+    if (hemocell.iter % tmeas == 0) {
+      FluidStatistics finfo = FluidInfo::calculateVelocityStatistics(&hemocell);
+      ParticleStatistics pinfo = ParticleInfo::calculateForceStatistics(&hemocell);
+      std::printf("STAT %u %lu %lu %lu %.8f %.8f\n", hemocell.iter, CellInformationFunctionals::getTotalNumberOfCells(&hemocell),
+                  CellInformationFunctionals::getNumberOfCellsFromType(&hemocell, "RBC"), CellInformationFunctionals::getNumberOfCellsFromType(&hemocell, "PLT"),
+                  (param::u_lbm_max * 0.5) / finfo.avg, pinfo.avg * param::df * 1.0e12);
+    }
+  }
+  writeCellInfo_CSV(hemocell);
+  return 0;
+}

@@ -48,6 +48,7 @@ SIGNATURES = {
     "hcl_set_mask": (C.c_int, [VP, VP]),
     "hcl_init_equilibrium": (C.c_int, [VP, C.c_double, c_double_p]),
     "hcl_set_body_force": (C.c_int, [VP, c_double_p]),
+    "hcl_set_wall_velocity": (C.c_int, [VP, C.c_int, c_double_p]),
     "hcl_collide_stream": (C.c_int, [VP, C.c_int]),
     "hcl_collide_stream_part": (C.c_int, [VP, C.c_int]),
     "hcl_step_end": (C.c_int, [VP]),

@@ -1,0 +1,252 @@
+// Minimal stand-in for the Palabos names that HemoCell case drivers use on the hot path
+// (SURVEY.md §8b "Palabos names the in-scope drivers also call").  This is NOT Palabos: the lattice
+// object only records what the driver asked for (size, dynamics, bounce-back flags, periodicity, body
+// force) and forwards the work to libhemocell_amd.so through the C ABI.
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <vector>
+
+extern "C" {
+#include "hemocell_amd.h"
+}
+
+#ifndef HEMOCELL_T_DEFINED
+#define HEMOCELL_T_DEFINED
+typedef double T;                 // config/constant_defaults.h:117-119
+#endif
+typedef long int plint;           // config/constant_defaults.h:126-131
+typedef long unsigned int pluint;
+
+namespace plb {
+
+using ::plint;
+using ::pluint;
+
+inline void hc_check(int rc, const char *what) {
+  if (rc != 0) {   // the reference logs and exits (core/hemoCell.cpp:75-78)
+    std::cerr << "(HemoCell) (GPU backend) " << what << ": " << hc_last_error() << std::endl;
+    std::exit(1);
+  }
+}
+
+template <typename U, int N>
+struct Array {
+  U data[N];
+  Array() { for (int i = 0; i < N; i++) data[i] = U(); }
+  Array(U a, U b) { static_assert(N == 2, "2 components"); data[0] = a; data[1] = b; }
+  Array(U a, U b, U c) { static_assert(N == 3, "3 components"); data[0] = a; data[1] = b; data[2] = c; }
+  U &operator[](int i) { return data[i]; }
+  const U &operator[](int i) const { return data[i]; }
+};
+
+struct Dot3D { plint x, y, z; Dot3D(plint x_ = 0, plint y_ = 0, plint z_ = 0) : x(x_), y(y_), z(z_) {} };
+
+struct Box3D {
+  plint x0, x1, y0, y1, z0, z1;
+  Box3D(plint a = 0, plint b = 0, plint c = 0, plint d = 0, plint e = 0, plint f = 0) : x0(a), x1(b), y0(c), y1(d), z0(e), z1(f) {}
+  plint getNx() const { return x1 - x0 + 1; }
+  plint getNy() const { return y1 - y0 + 1; }
+  plint getNz() const { return z1 - z0 + 1; }
+};
+
+namespace descriptors {
+template <typename U>
+struct ForcedD3Q19Descriptor {
+  enum { d = 3, q = 19 };
+  struct ExternalField { enum { forceBeginsAt = 0, sizeOfForce = 3, numScalars = 3 }; };
+};
+}  // namespace descriptors
+
+// ---- dynamics objects: only their identity and omega matter
+template <typename U, template <typename> class D>
+struct Dynamics { virtual ~Dynamics() {} virtual bool isBoundary() const { return false; } virtual U getOmega() const { return U(1); } };
+template <typename U, template <typename> class D>
+struct GuoExternalForceBGKdynamics : Dynamics<U, D> {
+  U omega;
+  explicit GuoExternalForceBGKdynamics(U omega_) : omega(omega_) {}
+  U getOmega() const override { return omega; }
+};
+template <typename U, template <typename> class D>
+struct BounceBack : Dynamics<U, D> {
+  explicit BounceBack(U = U(1)) {}
+  bool isBoundary() const override { return true; }
+};
+
+struct MultiBlockManagement3D { plint nx = 0, ny = 0, nz = 0, envelope = 1; };
+struct BlockCommunicator3D {};
+struct CombinedStatistics {};
+template <typename U, template <typename> class D> struct MultiCellAccess3D {};
+
+struct DefaultMultiBlockPolicy3D {
+  MultiBlockManagement3D getMultiBlockManagement(plint nx, plint ny, plint nz, plint env = 1) const { MultiBlockManagement3D m; m.nx = nx; m.ny = ny; m.nz = nz; m.envelope = env; return m; }
+  BlockCommunicator3D *getBlockCommunicator() const { return nullptr; }
+  CombinedStatistics *getCombinedStatistics() const { return nullptr; }
+  template <typename U, template <typename> class D> MultiCellAccess3D<U, D> *getMultiCellAccess() const { return nullptr; }
+};
+inline DefaultMultiBlockPolicy3D defaultMultiBlockPolicy3D() { return DefaultMultiBlockPolicy3D(); }
+
+template <typename U>
+class MultiScalarField3D {
+ public:
+  MultiScalarField3D(plint nx_, plint ny_, plint nz_, U v = U()) : nx(nx_), ny(ny_), nz(nz_), data((size_t)nx_ * ny_ * nz_, v) {}
+  U &get(plint x, plint y, plint z) { return data[((size_t)x * ny + y) * nz + z]; }
+  const U &get(plint x, plint y, plint z) const { return data[((size_t)x * ny + y) * nz + z]; }
+  Box3D getBoundingBox() const { return Box3D(0, nx - 1, 0, ny - 1, 0, nz - 1); }
+  plint getNx() const { return nx; }
+  plint getNy() const { return ny; }
+  plint getNz() const { return nz; }
+  plint nx, ny, nz;
+  std::vector<U> data;
+};
+
+template <typename U>
+class VoxelizedDomain3D {
+ public:
+  explicit VoxelizedDomain3D(const MultiBlockManagement3D &m) : management(m) {}
+  const MultiBlockManagement3D &getMultiBlockManagement() const { return management; }
+  MultiBlockManagement3D management;
+};
+
+struct Periodicity3D {
+  bool p[3] = {false, false, false};
+  void toggleAll(bool v) { p[0] = p[1] = p[2] = v; }
+  void toggle(int axis, bool v) { p[axis] = v; }
+  bool get(int axis) const { return p[axis]; }
+};
+
+// The driver-facing lattice: a recorder in front of hc_lattice.  The device object is created on first
+// use because drivers keep changing the description (periodicity, flags) after lattice->initialize().
+template <typename U, template <typename> class D>
+class MultiBlockLattice3D {
+ public:
+  MultiBlockLattice3D(const MultiBlockManagement3D &m, BlockCommunicator3D *, CombinedStatistics *, MultiCellAccess3D<U, D> *, Dynamics<U, D> *background)
+      : nx(m.nx), ny(m.ny), nz(m.nz), omega(background ? background->getOmega() : U(1)), mask((size_t)m.nx * m.ny * m.nz, 0) { delete background; }
+  ~MultiBlockLattice3D() { if (dev) hcl_destroy(dev); }
+  Box3D getBoundingBox() const { return Box3D(0, nx - 1, 0, ny - 1, 0, nz - 1); }
+  plint getNx() const { return nx; }
+  plint getNy() const { return ny; }
+  plint getNz() const { return nz; }
+  void toggleInternalStatistics(bool) {}
+  Periodicity3D &periodicity() { dirty_layout = true; return per; }
+  void initialize() {}
+  void collideAndStream() { device(); hc_check(hcl_collide_stream(dev, 1), "collideAndStream"); }
+
+  // ---- used by the shims below and by hemo::HemoCell
+  hc_lattice *device() {
+    if (dev && !dirty_layout) { if (dirty_force) push_force(); return dev; }
+    if (dev && stepped) { std::cerr << "(HemoCell) (GPU backend) the lattice layout was changed after the first time step" << std::endl; std::exit(1); }
+    if (dev) { hcl_destroy(dev); dev = nullptr; }
+    int pr[3] = {per.p[0], per.p[1], per.p[2]};
+    hc_check(hc_init(0), "hc_init");
+    hc_check(hcl_create(&dev, (int)nx, (int)ny, (int)nz, pr, omega, 0, (int)nx, 1), "hcl_create");
+    std::vector<uint8_t> padded((size_t)(nx + 4) * ny * nz, 1);
+    for (plint x = -2; x < nx + 2; x++) {
+      plint sx = x;
+      if (sx < 0 || sx >= nx) { if (per.p[0]) sx = ((sx % nx) + nx) % nx; else continue; }
+      std::copy(mask.begin() + (size_t)sx * ny * nz, mask.begin() + (size_t)(sx + 1) * ny * nz, padded.begin() + (size_t)(x + 2) * ny * nz);
+    }
+    hc_check(hcl_set_mask(dev, padded.data()), "hcl_set_mask");
+    for (size_t k = 0; k < wall_u.size(); k++) { double w[3] = {wall_u[k][0], wall_u[k][1], wall_u[k][2]}; hc_check(hcl_set_wall_velocity(dev, 3 + (int)k, w), "hcl_set_wall_velocity"); }
+    double u[3] = {eq_u[0], eq_u[1], eq_u[2]};
+    hc_check(hcl_init_equilibrium(dev, eq_rho, u), "hcl_init_equilibrium");
+    dirty_layout = false; dirty_force = true;
+    push_force();
+    return dev;
+  }
+  void push_force() { double f[3] = {body[0], body[1], body[2]}; hc_check(hcl_set_body_force(dev, f), "hcl_set_body_force"); dirty_force = false; }
+  void mark_stepped() { stepped = true; }
+
+  // velocity-wall classes (mask values 3..6), helper/hemocellInit.hh:71-86
+  int wall_class(U a, U b, U c) {
+    for (size_t k = 0; k < wall_u.size(); k++) if (wall_u[k][0] == a && wall_u[k][1] == b && wall_u[k][2] == c) return 3 + (int)k;
+    if (wall_u.size() == 4) { std::cerr << "(HemoCell) (GPU backend) at most four distinct wall velocities are supported" << std::endl; std::exit(1); }
+    wall_u.push_back({a, b, c});
+    return 3 + (int)wall_u.size() - 1;
+  }
+  std::vector<std::array<U, 3>> wall_u;
+
+  plint nx, ny, nz;
+  U omega;
+  std::vector<uint8_t> mask;   // 1 = BounceBack / isBoundary, 3..6 = velocity wall classes
+  Periodicity3D per;
+  U eq_rho = 1; U eq_u[3] = {0, 0, 0};
+  U body[3] = {0, 0, 0};
+  bool dirty_layout = true, dirty_force = true, stepped = false;
+  hc_lattice *dev = nullptr;
+};
+
+// defineDynamics(lattice, flagMatrix, bbox, new BounceBack(1.), flag)   (examples/pipeflow/pipeflow.cpp:73)
+template <typename U, template <typename> class D>
+void defineDynamics(MultiBlockLattice3D<U, D> &lattice, MultiScalarField3D<int> &flags, Box3D box, Dynamics<U, D> *dyn, int whichFlag) {
+  const bool wall = dyn->isBoundary();
+  for (plint x = box.x0; x <= box.x1; x++)
+    for (plint y = box.y0; y <= box.y1; y++)
+      for (plint z = box.z0; z <= box.z1; z++)
+        if (flags.get(x, y, z) == whichFlag) lattice.mask[((size_t)x * lattice.ny + y) * lattice.nz + z] = wall ? 1 : 0;
+  lattice.dirty_layout = true;
+  delete dyn;
+}
+// box form (e.g. cases with explicit wall slabs)
+template <typename U, template <typename> class D>
+void defineDynamics(MultiBlockLattice3D<U, D> &lattice, Box3D box, Dynamics<U, D> *dyn) {
+  const bool wall = dyn->isBoundary();
+  for (plint x = box.x0; x <= box.x1; x++)
+    for (plint y = box.y0; y <= box.y1; y++)
+      for (plint z = box.z0; z <= box.z1; z++) lattice.mask[((size_t)x * lattice.ny + y) * lattice.nz + z] = wall ? 1 : 0;
+  lattice.dirty_layout = true;
+  delete dyn;
+}
+
+// setExternalVector(lattice, bbox, forceBeginsAt, F)   (core/hemoCell.cpp:369-371, examples/pipeflow/pipeflow.cpp:144-146)
+template <typename U, template <typename> class D>
+void setExternalVector(MultiBlockLattice3D<U, D> &lattice, Box3D, int, Array<U, 3> F) {
+  if (F[0] != lattice.body[0] || F[1] != lattice.body[1] || F[2] != lattice.body[2]) { lattice.body[0] = F[0]; lattice.body[1] = F[1]; lattice.body[2] = F[2]; lattice.dirty_force = true; }
+}
+
+// ---- boundary-condition names of examples/stretchCell/stretchCell.cpp:74-79 and helper/hemocellInit.hh:71-86.
+// A "velocity condition" node becomes a no-slip wall node moving with the velocity given by
+// setBoundaryVelocity (full-way bounce-back + Ladd momentum term inside the library).  Palabos' regularised
+// velocity nodes are isBoundary() as well, so the IBM treats both alike.
+template <typename U, template <typename> class D>
+struct OnLatticeBoundaryCondition3D {
+  void setVelocityConditionOnBlockBoundaries(MultiBlockLattice3D<U, D> &l) {
+    for (plint x = 0; x < l.nx; x++) for (plint y = 0; y < l.ny; y++) for (plint z = 0; z < l.nz; z++)
+      if (x == 0 || y == 0 || z == 0 || x == l.nx - 1 || y == l.ny - 1 || z == l.nz - 1) l.mask[((size_t)x * l.ny + y) * l.nz + z] = 1;
+    l.dirty_layout = true;
+  }
+  void setVelocityConditionOnBlockBoundaries(MultiBlockLattice3D<U, D> &l, Box3D b) {
+    for (plint x = b.x0; x <= b.x1; x++) for (plint y = b.y0; y <= b.y1; y++) for (plint z = b.z0; z <= b.z1; z++) l.mask[((size_t)x * l.ny + y) * l.nz + z] = 1;
+    l.dirty_layout = true;
+  }
+};
+template <typename U, template <typename> class D>
+OnLatticeBoundaryCondition3D<U, D> *createLocalBoundaryCondition3D() { return new OnLatticeBoundaryCondition3D<U, D>(); }
+template <typename U, template <typename> class D>
+void setBoundaryVelocity(MultiBlockLattice3D<U, D> &l, Box3D b, Array<U, 3> v) {
+  const bool still = (v[0] == 0 && v[1] == 0 && v[2] == 0);
+  const int cls = still ? 1 : l.wall_class(v[0], v[1], v[2]);
+  for (plint x = b.x0; x <= b.x1; x++) for (plint y = b.y0; y <= b.y1; y++) for (plint z = b.z0; z <= b.z1; z++) {
+    uint8_t &m = l.mask[((size_t)x * l.ny + y) * l.nz + z];
+    if (m != 0) m = (uint8_t)cls;   // only nodes that carry a velocity condition
+  }
+  l.dirty_layout = true;
+}
+
+template <typename U, template <typename> class D>
+std::string getMultiBlockInfo(MultiBlockLattice3D<U, D> &l) {
+  return "Size of the lattice: " + std::to_string(l.nx) + "-by-" + std::to_string(l.ny) + "-by-" + std::to_string(l.nz) + " (one slab on one GPU)";
+}
+
+struct Pcout { template <typename V> Pcout &operator<<(const V &v) { std::cout << v; return *this; } Pcout &operator<<(std::ostream &(*f)(std::ostream &)) { std::cout << f; return *this; } };
+static Pcout pcout;
+typedef std::ofstream plb_ofstream;
+
+}  // namespace plb

@@ -59,6 +59,7 @@ struct hc_lattice {
   uint8_t *mask;         // [npad]
   std::vector<uint8_t> hmask;  // host copy (cell placement tests against it)
   double body[3];
+  double wall_u[4][3];   // velocities of the moving-wall mask classes 3..6
   // active-node map of the collide kernel: per padded plane and row, the z-span that holds every node
   // which is not an inert solid, flattened so that a launch only creates threads for those spans
   int *row_z0, *row_cum, *blk_row;   // [NX*ny], [NX*(ny+1)], [NX*(nblk+1)]

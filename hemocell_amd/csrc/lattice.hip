@@ -40,6 +40,7 @@ struct LatArgs {
   double bx, by, bz;
   const int *row_z0, *row_cum, *blk_row;
   int nblk;
+  double wall_u[4][3];   // moving-wall classes 3..6
 };
 
 struct Nbr {  // element offsets to the -1 / +1 neighbour along each axis, and validity
@@ -183,6 +184,19 @@ __global__ __launch_bounds__(256) void collide_stream_kernel(LatArgs a) {
     // BounceBack::collide: swap opposite pairs (full-way bounce-back)
 #pragma unroll
     for (int i = 1; i <= 9; i++) { double t = f[i]; f[i] = f[i + 9]; f[i + 9] = t; }
+    if (m >= 3) {
+      // moving no-slip wall: Ladd's momentum term at rho = 1, f_opp(i) = f_i - 6 t_i (c_i.u_w); after the
+      // swap slot o holds f_i, so the term of direction i = opp(o) is subtracted from slot o
+      const double w0 = a.wall_u[m - 3][0], w1 = a.wall_u[m - 3][1], w2 = a.wall_u[m - 3][2];
+#define M(Q, CX, CY, CZ)                                                                  \
+      if (Q != 0) {                                                                       \
+        constexpr int O = Q <= 9 ? Q + 9 : Q - 9;                                         \
+        const double c_u = (double)CX * w0 + (double)CY * w1 + (double)CZ * w2;           \
+        f[O] = f[O] - 6.0 * tq(Q) * c_u;                                                  \
+      }
+      FOR_Q(M)
+#undef M
+    }
   } else {
     const double Fx = a.bx + a.Fin[node], Fy = a.by + a.Fin[a.npad + node], Fz = a.bz + a.Fin[2 * a.npad + node];
     collide_guo(f, Fx, Fy, Fz, a.omega);
@@ -307,6 +321,7 @@ LatArgs make_args(const hc_lattice *L) {
   a.per_y = L->periodic[1]; a.per_z = L->periodic[2];
   a.omega = L->omega; a.bx = L->body[0]; a.by = L->body[1]; a.bz = L->body[2];
   a.row_z0 = L->row_z0; a.row_cum = L->row_cum; a.blk_row = L->blk_row; a.nblk = L->nblk;
+  for (int c = 0; c < 4; c++) for (int d = 0; d < 3; d++) a.wall_u[c][d] = L->wall_u[c][d];
   return a;
 }
 
@@ -393,6 +408,7 @@ int hcl_create(hc_lattice **out, int nx, int ny, int nz, const int periodic[3], 
   L->npad = (size_t)(nx + 2 * HALO) * L->plane;
   L->cur = 0; L->fcur = 0;
   L->body[0] = L->body[1] = L->body[2] = 0.0;
+  for (int c = 0; c < 4; c++) for (int d = 0; d < 3; d++) L->wall_u[c][d] = 0.0;
   L->scratch = nullptr; L->scratch_doubles = 0;
   L->f[0] = L->f[1] = L->force[0] = L->force[1] = nullptr; L->mask = nullptr;
   for (int k = 0; k < 2; k++) {
@@ -433,7 +449,7 @@ int hcl_dims(const hc_lattice *L, int dims[3]) {
 int hcl_set_mask(hc_lattice *L, const uint8_t *mask_with_halo) {
   HC_REQUIRE(L && mask_with_halo, "hcl_set_mask: null pointer");
   L->hmask.assign(mask_with_halo, mask_with_halo + L->npad);
-  for (auto &m : L->hmask) m = m ? 1 : 0;
+  for (auto &m : L->hmask) m = (m >= 3 && m <= 6) ? m : (m ? 1 : 0);   // 1 = bounce-back, 3..6 = moving-wall classes
   // class 2 = solid node without any fluid neighbour.  Full-way bounce-back returns every population to
   // where it came from, so such a node never exchanges anything with the fluid: the collide kernel skips
   // it (no loads, no stores).  Results on fluid nodes are unchanged, bit for bit.
@@ -484,6 +500,12 @@ int hcl_init_equilibrium(hc_lattice *L, double rho, const double u[3]) {
   hipLaunchKernelGGL(init_eq_kernel, plane_grid(L, L->nx), dim3(256), 0, hc::stream(), a, rho - 1.0, rho * u[0], rho * u[1], rho * u[2]);
   HC_HIP(hipGetLastError());
   HC_HIP(hipStreamSynchronize(hc::stream()));
+  return HC_OK;
+}
+
+int hcl_set_wall_velocity(hc_lattice *L, int wall_class, const double u[3]) {
+  HC_REQUIRE(L && u && wall_class >= 3 && wall_class <= 6, "hcl_set_wall_velocity: class must be 3..6");
+  for (int d = 0; d < 3; d++) L->wall_u[wall_class - 3][d] = u[d];
   return HC_OK;
 }
 

@@ -74,7 +74,7 @@ class Lattice:
         if self.periodic[0]:
             local = m[np.mod(xs, self.nx_global)]
         else:
-            local = np.ones((len(xs), self.ny, self.nz), np.uint8)
+            local = np.ones((len(xs), self.ny, self.nz), np.uint8)   # outside a non-periodic pipe end: wall
             ok = (xs >= 0) & (xs < self.nx_global)
             local[ok] = m[xs[ok]]
         local = np.ascontiguousarray(local)
@@ -87,6 +87,11 @@ class Lattice:
     def setExternalVector(self, F):
         ff = np.array(F, dtype=np.float64)
         check(self.lib.hcl_set_body_force(self.ptr, dptr(ff)))
+
+    def setBoundaryVelocity(self, wall_class, u):
+        """velocity of the nodes whose mask value is wall_class (3..6)"""
+        uu = np.array(u, dtype=np.float64)
+        check(self.lib.hcl_set_wall_velocity(self.ptr, int(wall_class), dptr(uu)))
 
     def collideAndStream(self, steps=1):
         check(self.lib.hcl_collide_stream(self.ptr, int(steps)))

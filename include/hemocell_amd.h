@@ -62,7 +62,7 @@ int hcl_create(hc_lattice **out, int nx, int ny, int nz, const int periodic[3], 
                int x0, int nx_global, int n_slabs);
 int hcl_destroy(hc_lattice *L);
 /* defineDynamics(lattice, flagMatrix, bbox, new BounceBack(1.), 0) (examples/pipeflow/pipeflow.cpp:73):
- * mask[node]=1 -> full-way bounce-back / isBoundary; node = z + nz*(y + ny*x_local), x_local in [-2, nx+2)
+ * mask[node]=1 -> full-way bounce-back / isBoundary (3..6: moving wall classes, see hcl_set_wall_velocity); node = z + nz*(y + ny*x_local), x_local in [-2, nx+2)
  * i.e. the array holds (nx+4)*ny*nz bytes including the halo planes. */
 int hcl_set_mask(hc_lattice *L, const uint8_t *mask_with_halo);
 /* HemoCell::latticeEquilibrium(rho,u) + lattice->initialize() (core/hemoCell.cpp:129-133) */
@@ -70,6 +70,10 @@ int hcl_init_equilibrium(hc_lattice *L, double rho, const double u[3]);
 /* setExternalVector(lattice, bbox, forceBeginsAt, F) (core/hemoCell.cpp:369-371, examples/pipeflow/pipeflow.cpp:144-146):
  * the uniform driving force; the per-node IBM force is kept separately and zeroed by the collide kernel */
 int hcl_set_body_force(hc_lattice *L, const double F[3]);
+/* setBoundaryVelocity(lattice, box, u) on nodes flagged by setVelocityConditionOnBlockBoundaries
+ * (helper/hemocellInit.hh:71-86): mask classes 3..6 are moving no-slip walls with velocity u (full-way
+ * bounce-back + Ladd momentum term; stand-in for Palabos' regularised boundary, which is not available) */
+int hcl_set_wall_velocity(hc_lattice *L, int wall_class, const double u[3]);
 /* lattice->collideAndStream() (core/hemoCell.cpp:317), n times (fluid-only stepping; n_slabs==1) */
 int hcl_collide_stream(hc_lattice *L, int nsteps);
 /* one collide-stream of this slab; halos must be current. part: 0 = all planes, 1 = interior planes

@@ -47,6 +47,7 @@ void orc_lattice_destroy(orc_lattice *L) {
   free(L->f); free(L->ftmp); free(L->force); free(L->mask); free(L);
 }
 void orc_lattice_set_threads(orc_lattice *L, int n) { L->nthreads = n < 1 ? 1 : n; }
+void orc_lattice_set_wall_velocity(orc_lattice *L, int cls, const double u[3]) { for (int d = 0; d < 3; d++) L->wall_u[cls][d] = u[d]; }
 void orc_lattice_set_mask(orc_lattice *L, const unsigned char *mask) {
   memcpy(L->mask, mask, (size_t)L->nx * L->ny * L->nz);
 }
@@ -127,6 +128,19 @@ static void collide_guo_bgk(double *f, const double *F, double omega) {
 static void collide_bounce_back(double *f) {
   for (int i = 1; i <= 9; i++) { double t = f[i]; f[i] = f[i + 9]; f[i + 9] = t; }
 }
+/* Moving no-slip wall (mask classes 3..6): full-way bounce-back with Ladd's momentum term at rho = 1,
+ * f_opp(i) = f_i - 2 t_i (c_i.u_w)/cs^2.  This is the stand-in for Palabos' regularised velocity boundary
+ * (createLocalBoundaryCondition3D, examples/oneCellShear/oneCellShear.cpp:62-66), which is not available;
+ * the two agree on the flow they impose, not bit for bit (UNPINNED). */
+static void collide_moving_wall(double *f, const double *uw) {
+  double in[ORC_Q];
+  for (int i = 0; i < ORC_Q; i++) in[i] = f[i];
+  for (int i = 1; i < ORC_Q; i++) {
+    const int o = i <= 9 ? i + 9 : i - 9;
+    const double c_u = orc_c[i][0] * uw[0] + orc_c[i][1] * uw[1] + orc_c[i][2] * uw[2];
+    f[o] = in[i] - 6.0 * orc_t[i] * c_u;
+  }
+}
 
 /* MultiBlockLattice3D::collideAndStream (core/hemoCell.cpp:317): collide every
  * node, then stream f_i(x+c_i) <- f*_i(x) with periodic wrap
@@ -143,7 +157,8 @@ void orc_collide_stream(orc_lattice *L) {
 #pragma omp parallel for num_threads(L->nthreads) schedule(static)
 #endif
   for (long k = 0; k < n; k++) {
-    if (L->mask[k]) collide_bounce_back(L->ftmp + k * ORC_Q);
+    if (L->mask[k] >= 3) collide_moving_wall(L->ftmp + k * ORC_Q, L->wall_u[L->mask[k] - 3]);
+    else if (L->mask[k]) collide_bounce_back(L->ftmp + k * ORC_Q);
     else collide_guo_bgk(L->ftmp + k * ORC_Q, L->force + 3 * k, L->omega);
   }
 #ifdef _OPENMP

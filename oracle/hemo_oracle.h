@@ -32,8 +32,9 @@ typedef struct orc_lattice {
   double *f;               /* [n][19] AoS, stored as f_i - t_i (Palabos fBar convention)   */
   double *ftmp;            /* second buffer for collide -> stream                          */
   double *force;           /* [n][3]  Cell::external.data[0..2]                            */
-  unsigned char *mask;     /* 0 = GuoExternalForceBGKdynamics, 1 = BounceBack (isBoundary) */
+  unsigned char *mask;     /* 0 = GuoExternalForceBGKdynamics, 1 = BounceBack (isBoundary), 3..6 = moving wall class */
   int nthreads;            /* OpenMP threads used by orc_collide_stream (cpu_baseline)     */
+  double wall_u[4][3];     /* velocity of the moving-wall classes 3..6                     */
 } orc_lattice;
 
 orc_lattice *orc_lattice_create(int nx, int ny, int nz, const int periodic[3], double omega);
@@ -45,6 +46,7 @@ void orc_collide_stream(orc_lattice *L);
 /* rho and u = j/rho + F/2 of the current (post-stream) populations */
 void orc_node_rho_u(const orc_lattice *L, long node, double *rho, double u[3]);
 void orc_lattice_set_threads(orc_lattice *L, int n);
+void orc_lattice_set_wall_velocity(orc_lattice *L, int cls, const double u[3]);
 
 /* D3Q19 tables (Palabos ordering) */
 extern const int    orc_c[ORC_Q][3];

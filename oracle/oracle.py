@@ -20,7 +20,7 @@ c_int_p = C.POINTER(C.c_int)
 class Lattice(C.Structure):
     _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("periodic", C.c_int * 3),
                 ("omega", C.c_double), ("f", c_double_p), ("ftmp", c_double_p), ("force", c_double_p),
-                ("mask", C.POINTER(C.c_ubyte)), ("nthreads", C.c_int)]
+                ("mask", C.POINTER(C.c_ubyte)), ("nthreads", C.c_int), ("wall_u", (C.c_double * 3) * 4)]
 
 
 class Params(C.Structure):
@@ -81,6 +81,7 @@ def load():
         "orc_lattice_set_force_uniform": (None, [LP, c_double_p]),
         "orc_collide_stream": (None, [LP]),
         "orc_lattice_set_threads": (None, [LP, C.c_int]),
+        "orc_lattice_set_wall_velocity": (None, [LP, C.c_int, c_double_p]),
         "orc_node_rho_u": (None, [LP, C.c_long, c_double_p, c_double_p]),
         "orc_params_base": (None, [C.POINTER(Params)] + [C.c_double] * 5),
         "orc_celltype_create": (TP, [C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, c_long_p, C.c_int]),
@@ -143,6 +144,10 @@ class OracleLattice:
 
     def set_threads(self, n):
         self.lib.orc_lattice_set_threads(self.ptr, n)
+
+    def set_wall_velocity(self, cls, u):
+        uu = np.array(u, dtype=np.float64)
+        self.lib.orc_lattice_set_wall_velocity(self.ptr, cls, dptr(uu))
 
     def collide_stream(self, steps=1):
         for _ in range(steps):

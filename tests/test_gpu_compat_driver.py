@@ -1,0 +1,91 @@
+"""GPU runs of the example drivers written against the C++ facade; the assertions are the reference's own
+validation bounds, so these read like tests/validation/* of the reference."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _build(tmp_path, example):
+    from hemocell_amd import capi
+    out = str(tmp_path / "drv")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wno-deprecated-declarations", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "hemocell_amd", "compat"), os.path.join(ROOT, example), "-o", out,
+                           "-L" + libdir, "-lhemocell_amd", "-Wl,-rpath," + libdir])
+    return out
+
+
+def test_stretch_driver_matches_python_host_and_band(tmp_path, gpu):
+    """tests/validation/stretch_cell/test_stretch_cell.cpp:158: 25 pN -> transverse 7.3-7.9 um, axial 9.2-9.7 um;
+    the C++ facade and the Python host drive the same library, so their trajectories are identical"""
+    exe = _build(tmp_path, "examples/stretch/stretch_cell.cpp")
+    r = subprocess.run([exe, "config.xml", "25", "10000"], cwd=os.path.join(ROOT, "examples", "stretch"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = [list(map(float, l.split()[1:])) for l in r.stdout.splitlines() if l.startswith("RESULT")]
+    assert "CELLS 1" in r.stdout
+    it, axial, transverse, vratio = rows[-1]
+    assert it == 10000 and 7.3 <= transverse <= 7.9 and 9.2 <= axial <= 9.7 and 0.98 < vratio <= 1.02, rows[-1]
+    # same case through the Python host layer
+    P = gpu.base_parameters(dt=1e-7)
+    nx, ny, nz = 52, 26, 26
+    mask = np.zeros((nx, ny, nz), np.uint8)
+    mask[0] = mask[-1] = 1; mask[:, 0] = mask[:, -1] = 1; mask[:, :, 0] = mask[:, :, -1] = 1
+    L = gpu.Lattice(nx, ny, nz, (0, 0, 0), 1.0 / P.tau); L.defineBounceBack(mask); L.latticeEquilibrium()
+    h = gpu.HemoCell(L, P); h.cellfields.addCellType(gpu.CellType.rbc(P), 1)
+    assert h.cellfields.addCell(0, (24.0, 12.0, 12.0), (90, 0, 0))
+    pos = h.cellfields.positions
+    order = np.argsort(pos[:, 0], kind="stable")
+    idx = np.concatenate([order[:7], order[-7:]])
+    f = 25.0 * 1e-12 / P.df / 7
+    ff = np.zeros((14, 3)); ff[:7, 0] = -f; ff[7:, 0] = f
+    h.cellfields.applyConstitutiveModel(0, True)
+    for _ in range(1000):
+        h.cellfields.addVertexForce(idx, ff); h.iterate(1)
+    bb = h.cellfields.cell_info(0)["bbox"][0] / 2.0
+    row1000 = [x for x in rows if x[0] == 1000][0]
+    assert abs((bb[1] - bb[0]) - row1000[1]) < 1e-9 and abs((bb[3] - bb[2]) - row1000[2]) < 1e-9
+    L.destroy()
+
+
+def test_pipe_driver_validation_bounds(tmp_path, gpu):
+    """tests/validation/pipeflow/test_pipeflow.cpp:87-106 on the synthetic pipe: the cell count stays constant,
+    relative apparent viscosity in (1.03, 3.0), mean vertex force below 4 pN"""
+    exe = _build(tmp_path, "examples/pipe/pipe_synthetic.cpp")
+    r = subprocess.run([exe, "config.xml"], cwd=os.path.join(ROOT, "examples", "pipe"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    stats = [l.split()[1:] for l in r.stdout.splitlines() if l.startswith("STAT")]
+    assert len(stats) == 4
+    counts = {int(s[1]) for s in stats}
+    assert len(counts) == 1 and counts.pop() == 30          # 25 RBC + 5 PLT, none lost
+    for s in stats:
+        visc, force = float(s[4]), float(s[5])
+        assert 1.03 < visc < 3.0, s
+        assert force < 4.0, s
+
+
+def test_moving_wall_couette_vs_oracle(orc, gpu):
+    """helper/hemocellInit.hh:71-86 (oneCellShear): top/bottom walls moving in +-x, x and y periodic.  GPU vs
+    oracle bit for bit, and the steady profile is linear with the imposed shear rate."""
+    from oracle import oracle as O
+    nx, ny, nz = 8, 6, 22
+    mask = np.zeros((nx, ny, nz), np.uint8); mask[:, :, 0] = 3; mask[:, :, -1] = 4
+    shear = 1e-4; vhalf = (nz - 1) * shear * 0.5
+    Lo = O.OracleLattice(orc, nx, ny, nz, (1, 1, 0), 1.0); Lg = gpu.Lattice(nx, ny, nz, (1, 1, 0), 1.0)
+    Lo.set_mask(mask); Lg.defineBounceBack(mask)
+    Lo.set_wall_velocity(0, (vhalf, 0, 0)); Lo.set_wall_velocity(1, (-vhalf, 0, 0))
+    Lg.setBoundaryVelocity(3, (vhalf, 0, 0)); Lg.setBoundaryVelocity(4, (-vhalf, 0, 0))
+    Lo.init_equilibrium(); Lg.latticeEquilibrium()
+    Lo.collide_stream(3000); Lg.collideAndStream(3000)
+    fluid = mask.reshape(-1) == 0
+    assert np.array_equal(Lg.populations()[fluid], Lo.f[fluid])
+    rho, u = Lg.rho_u()
+    ux = u[:, 0].reshape(nx, ny, nz)[0, 0, 1:-1]
+    z = np.arange(1, nz - 1)
+    expect = vhalf - (z - 0.5) * (2 * vhalf) / (nz - 2)      # walls sit half a node outside the first/last fluid node
+    assert np.abs(ux - expect).max() < 0.02 * vhalf
+    Lo.destroy(); Lg.destroy()

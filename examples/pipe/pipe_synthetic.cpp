@@ -43,6 +43,11 @@ int main(int argc, char *argv[]) {
   hemocell.addCellType<PltSimpleModel>("PLT", ELLIPSOID_FROM_SPHERE);
   hemocell.setMaterialTimeScaleSeparation("PLT", (*cfg)["ibm"]["stepMaterialEvery"].read<int>());
   hemocell.setParticleVelocityUpdateTimeScaleSeparation((*cfg)["ibm"]["stepParticleEvery"].read<int>());
+  vector<int> outputs = {OUTPUT_POSITION, OUTPUT_TRIANGLES, OUTPUT_FORCE, OUTPUT_FORCE_VOLUME, OUTPUT_FORCE_BENDING, OUTPUT_FORCE_LINK, OUTPUT_FORCE_AREA, OUTPUT_FORCE_VISC, OUTPUT_CELL_ID, OUTPUT_VERTEX_ID};
+  hemocell.setOutputs("RBC", outputs);
+  outputs.push_back(OUTPUT_INNER_LINKS); outputs.push_back(OUTPUT_FORCE_INNER_LINK);
+  hemocell.setOutputs("PLT", outputs);
+  hemocell.setFluidOutputs({OUTPUT_VELOCITY, OUTPUT_DENSITY, OUTPUT_FORCE, OUTPUT_BOUNDARY});
   hemocell.setSystemPeriodicity(0, true);
   hemocell.loadParticles();
 
@@ -63,6 +68,6 @@ int main(int argc, char *argv[]) {
                   (param::u_lbm_max * 0.5) / finfo.avg, pinfo.avg * param::df * 1.0e12);
     }
   }
-  writeCellInfo_CSV(hemocell);
+  hemocell.writeOutput();   // <out>/hdf5/<iter>/{RBC,PLT,Fluid}.<iter>.p.0.h5 + <out>/csv
   return 0;
 }

@@ -1,0 +1,139 @@
+// HDF5 output with the reference's file layout (row f, rank 2 of SURVEY.md §8):
+//   <out>/hdf5/<iter %012d>/<Name>.<iter %012d>.p.<blockId>.h5        io/ParticleHdf5IO.cpp:60, io/FluidHdf5IO.hh:89
+// Cell files: root attributes dx, dt, iteration, processorId, numberOfProcessors, numberOfParticles,
+// numberOfTriangles; float32 [n][3|1] datasets named as io/hemoCellParticleFieldOutputFunctions.cpp:53-426,
+// int32 "Triangles" / "InnerLinks" with per-cell vertex offsets; chunks of <= 1000 rows, deflate 7
+// (io/ParticleHdf5IO.cpp:85-151).  Fluid file: attributes numberOfCells, subdomainSize {Nz,Ny,Nx},
+// relativePosition {z,y,x} - 1.5, dxdydz; float32 [Nz+2][Ny+2][Nx+2][C] datasets incl. a one-node envelope,
+// SI scaling when outputInSiUnits (io/FluidHdf5IO.hh:92-287).  Compiled only when HEMOCELL_WITH_HDF5 is defined.
+#pragma once
+#ifdef HEMOCELL_WITH_HDF5
+#include <hdf5.h>
+#include <hdf5_hl.h>
+#include "hemocell.h"
+
+namespace hemo {
+
+inline string zeroPadNumber(unsigned int n) { char b[32]; std::snprintf(b, sizeof(b), "%012u", n); return b; }
+
+inline void h5_write_2d(hid_t file, const string &name, const vector<float> &data, hsize_t rows, hsize_t cols) {
+  hsize_t dim[2] = {rows, cols};
+  hsize_t chunk[2] = {std::max<hsize_t>(1, std::min<hsize_t>(1000, rows)), std::max<hsize_t>(1, cols)};
+  hid_t sid = H5Screate_simple(2, dim, NULL), pl = H5Pcreate(H5P_DATASET_CREATE);
+  H5Pset_chunk(pl, 2, chunk); H5Pset_deflate(pl, 7);
+  hid_t did = H5Dcreate2(file, name.c_str(), H5T_NATIVE_FLOAT, sid, H5P_DEFAULT, pl, H5P_DEFAULT);
+  H5Dwrite(did, H5T_NATIVE_FLOAT, H5S_ALL, H5S_ALL, H5P_DEFAULT, data.data());
+  H5Dclose(did); H5Pclose(pl); H5Sclose(sid);
+}
+inline void h5_write_2d_int(hid_t file, const string &name, const vector<int> &data, hsize_t rows, hsize_t cols) {
+  hsize_t dim[2] = {rows, cols};
+  hsize_t chunk[2] = {std::max<hsize_t>(1, std::min<hsize_t>(1000, rows)), std::max<hsize_t>(1, cols)};
+  hid_t sid = H5Screate_simple(2, dim, NULL), pl = H5Pcreate(H5P_DATASET_CREATE);
+  H5Pset_chunk(pl, 2, chunk); H5Pset_deflate(pl, 7);
+  hid_t did = H5Dcreate2(file, name.c_str(), H5T_NATIVE_INT, sid, H5P_DEFAULT, pl, H5P_DEFAULT);
+  H5Dwrite(did, H5T_NATIVE_INT, H5S_ALL, H5S_ALL, H5P_DEFAULT, data.data());
+  H5Dclose(did); H5Pclose(pl); H5Sclose(sid);
+}
+
+// writeCellField3D_HDF5 (io/ParticleHdf5IO.cpp:36-176)
+inline void writeCellField3D_HDF5(HemoCell &h, HemoCellField &field, const string &dir) {
+  if (field.desiredOutputVariables.empty()) return;
+  hc_cells *c = h.cellfields->device();
+  long fv = 0, nc = 0; hcp_type_range(c, (int)field.ctype, &fv, &nc);
+  long nvt = 0, nct = 0; hcp_counts(c, &nvt, &nct, nullptr);
+  const long n = nc * field.numVertex;
+  vector<double> pos(3 * (size_t)nvt), vel(3 * (size_t)nvt), frc(3 * (size_t)nvt), comp;
+  if (nvt) { hcp_download(c, 0, pos.data()); hcp_download(c, 1, vel.data()); hcp_download(c, 2, frc.data()); }
+  vector<long> ids((size_t)nct); if (nct) hcp_download_cell_ids(c, ids.data());
+  long first_cell = 0; for (unsigned int t = 0; t < field.ctype; t++) { long f2, n2; hcp_type_range(c, (int)t, &f2, &n2); first_cell += n2; }
+  const string fileName = dir + "/" + field.name + "." + zeroPadNumber(h.iter) + ".p.0.h5";
+  hid_t file = H5Fcreate(fileName.c_str(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+  double dx = Parameters::dx, dt = Parameters::dt; long it = h.iter, np_ = 1; int id = 0;
+  H5LTset_attribute_double(file, "/", "dx", &dx, 1); H5LTset_attribute_double(file, "/", "dt", &dt, 1);
+  H5LTset_attribute_long(file, "/", "iteration", &it, 1); H5LTset_attribute_int(file, "/", "processorId", &id, 1);
+  H5LTset_attribute_long(file, "/", "numberOfProcessors", &np_, 1);
+  const bool si = h.outputInSiUnits;
+  auto vec3 = [&](const vector<double> &src, double scale) { vector<float> o(3 * (size_t)n); for (long i = 0; i < 3 * n; i++) o[(size_t)i] = (float)(src[(size_t)(3 * fv + i)] * scale); return o; };
+  bool triangles = false, innerlinks = false;
+  for (int var : field.desiredOutputVariables) {
+    switch (var) {
+      case OUTPUT_POSITION: { h5_write_2d(file, "Position", vec3(pos, si ? Parameters::dx : 1.0), n, 3); long nP = n; H5LTset_attribute_long(file, "/", "numberOfParticles", &nP, 1); break; }
+      case OUTPUT_VELOCITY: h5_write_2d(file, "Velocity", vec3(vel, si ? Parameters::dx / Parameters::dt : 1.0), n, 3); break;
+      case OUTPUT_FORCE: h5_write_2d(file, "Total force", vec3(frc, si ? Parameters::df : 1.0), n, 3); break;
+      case OUTPUT_FORCE_VOLUME: case OUTPUT_FORCE_AREA: case OUTPUT_FORCE_BENDING: case OUTPUT_FORCE_LINK: case OUTPUT_FORCE_VISC: case OUTPUT_FORCE_INNER_LINK: {
+        if (comp.empty() && n) { comp.resize(18 * (size_t)n); hc_check(hcp_mechanics_components(c, (int)field.ctype, comp.data()), "hcp_mechanics_components"); }
+        const int slot = var == OUTPUT_FORCE_VOLUME ? 0 : var == OUTPUT_FORCE_AREA ? 1 : var == OUTPUT_FORCE_BENDING ? 2 : var == OUTPUT_FORCE_LINK ? 3 : var == OUTPUT_FORCE_VISC ? 4 : 5;
+        static const char *names[6] = {"Volume force", "Area force", "Bending force", "Link force", "Viscous force", "Inner link force"};
+        vector<float> o(3 * (size_t)n); for (long i = 0; i < 3 * n; i++) o[(size_t)i] = (float)(comp[(size_t)(slot * 3 * n + i)] * (si ? Parameters::df : 1.0));
+        h5_write_2d(file, names[slot], o, n, 3); break; }
+      case OUTPUT_FORCE_REPULSION: h5_write_2d(file, "Repulsion force", vector<float>(3 * (size_t)n, 0.f), n, 3); break;
+      case OUTPUT_VERTEX_ID: { vector<float> o((size_t)n); for (long i = 0; i < n; i++) o[(size_t)i] = (float)(i % field.numVertex); h5_write_2d(file, "Vertex Id", o, n, 1); break; }
+      case OUTPUT_CELL_ID: { vector<float> o((size_t)n); for (long i = 0; i < n; i++) o[(size_t)i] = (float)ids[(size_t)(first_cell + i / field.numVertex)]; h5_write_2d(file, "Cell Id", o, n, 1); break; }
+      case OUTPUT_RES_TIME: h5_write_2d(file, "Res Time", vector<float>((size_t)n, 0.f), n, 1); break;
+      case OUTPUT_TRIANGLES: triangles = true; break;
+      case OUTPUT_INNER_LINKS: innerlinks = true; break;
+      default: break;
+    }
+  }
+  if (triangles) {   // vertex indices offset by numVertex per cell (io/hemoCellParticleFieldOutputFunctions.cpp:345-364)
+    vector<int> tri(3 * (size_t)(nc * field.numTriangles));
+    for (long cc = 0; cc < nc; cc++) for (int t = 0; t < field.numTriangles; t++) for (int k = 0; k < 3; k++)
+      tri[(size_t)((cc * field.numTriangles + t) * 3 + k)] = (int)(field.triangles[3 * (size_t)t + k] + cc * field.numVertex);
+    h5_write_2d_int(file, "Triangles", tri, (hsize_t)(nc * field.numTriangles), 3);
+    long nT = nc * field.numTriangles; H5LTset_attribute_long(file, "/", "numberOfTriangles", &nT, 1);
+  }
+  if (innerlinks && !field.innerEdges.empty()) {
+    const long ni = (long)field.innerEdges.size() / 2;
+    vector<int> li(2 * (size_t)(nc * ni));
+    for (long cc = 0; cc < nc; cc++) for (long e = 0; e < ni; e++) for (int k = 0; k < 2; k++) li[(size_t)((cc * ni + e) * 2 + k)] = (int)(field.innerEdges[2 * (size_t)e + k] + cc * field.numVertex);
+    h5_write_2d_int(file, "InnerLinks", li, (hsize_t)(nc * ni), 2);
+    long nL = nc * ni; H5LTset_attribute_long(file, "/", "numberOfInnerLinks", &nL, 1);
+  }
+  H5Fclose(file);
+}
+
+// writeFluidField_HDF5 (io/FluidHdf5IO.hh:60-210)
+inline void writeFluidField_HDF5(HemoCell &h, const string &dir) {
+  if (h.fluidOutputs.empty()) return;
+  auto *L = h.lattice; hc_lattice *d = L->device();
+  const plint nx = L->nx, ny = L->ny, nz = L->nz;
+  const size_t nn = (size_t)nx * ny * nz;
+  vector<double> rho(nn), u(3 * nn);
+  hc_check(hcl_download_rho_u(d, rho.data(), u.data()), "hcl_download_rho_u");
+  const string fileName = dir + "/Fluid." + zeroPadNumber(h.iter) + ".p.0.h5";
+  hid_t file = H5Fcreate(fileName.c_str(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+  double dx = Parameters::dx, dt = Parameters::dt; long it = h.iter; int id = 0;
+  H5LTset_attribute_double(file, "/", "dx", &dx, 1); H5LTset_attribute_double(file, "/", "dt", &dt, 1);
+  H5LTset_attribute_long(file, "/", "iteration", &it, 1); H5LTset_attribute_int(file, "/", "processorId", &id, 1);
+  const hsize_t Nx = nx + 2, Ny = ny + 2, Nz = nz + 2;   // one-node envelope on each side for paraview
+  int ncells = (int)(Nx * Ny * Nz); int sub[3] = {(int)Nz, (int)Ny, (int)Nx};
+  float dxdydz[3] = {1.f, 1.f, 1.f}, rel[3] = {-1.5f, -1.5f, -1.5f};
+  const bool si = h.outputInSiUnits;
+  if (si) for (int k = 0; k < 3; k++) { rel[k] *= (float)Parameters::dx; dxdydz[k] = (float)Parameters::dx; }
+  H5LTset_attribute_int(file, "/", "numberOfCells", &ncells, 1); H5LTset_attribute_int(file, "/", "subdomainSize", sub, 3);
+  H5LTset_attribute_float(file, "/", "relativePosition", rel, 3); H5LTset_attribute_float(file, "/", "dxdydz", dxdydz, 3);
+  auto src = [&](plint v, plint n, bool per) { if (v < 0 || v >= n) return per ? ((v % n) + n) % n : std::min<plint>(std::max<plint>(v, 0), n - 1); return v; };
+  auto write4 = [&](const string &name, int C, const std::function<float(size_t, int)> &val) {
+    vector<float> out((size_t)(Nx * Ny * Nz) * C); size_t o = 0;
+    for (plint z = -1; z <= nz; z++) for (plint y = -1; y <= ny; y++) for (plint x = -1; x <= nx; x++) {
+      const size_t k = ((size_t)src(x, nx, L->per.p[0]) * ny + src(y, ny, L->per.p[1])) * nz + src(z, nz, L->per.p[2]);
+      for (int cidx = 0; cidx < C; cidx++) out[o++] = val(k, cidx);
+    }
+    hsize_t dim[4] = {Nz, Ny, Nx, (hsize_t)C}, chunk[4] = {std::min<hsize_t>(1000, Nz), std::min<hsize_t>(1000, Ny), std::min<hsize_t>(1000, Nx), (hsize_t)C};
+    hid_t sid = H5Screate_simple(4, dim, NULL), pl = H5Pcreate(H5P_DATASET_CREATE);
+    H5Pset_chunk(pl, 4, chunk); H5Pset_deflate(pl, 7);
+    hid_t did = H5Dcreate2(file, name.c_str(), H5T_NATIVE_FLOAT, sid, H5P_DEFAULT, pl, H5P_DEFAULT);
+    H5Dwrite(did, H5T_NATIVE_FLOAT, H5S_ALL, H5S_ALL, H5P_DEFAULT, out.data());
+    H5Dclose(did); H5Pclose(pl); H5Sclose(sid);
+  };
+  for (int var : h.fluidOutputs) {
+    if (var == OUTPUT_VELOCITY) write4("Velocity", 3, [&](size_t k, int cidx) { return (float)(u[3 * k + cidx] * (si ? Parameters::dx / Parameters::dt : 1.0)); });
+    else if (var == OUTPUT_FORCE) write4("Force", 3, [&](size_t, int cidx) { return (float)(L->body[cidx] * (si ? Parameters::df : 1.0)); });
+    else if (var == OUTPUT_DENSITY) write4("Density", 1, [&](size_t k, int) { return (float)(rho[k] * (si ? Parameters::df / (Parameters::dx * Parameters::dx) : 1.0)); });
+    else if (var == OUTPUT_BOUNDARY) write4("Boundary", 1, [&](size_t k, int) { return L->mask[k] ? 1.f : 0.f; });
+  }
+  H5Fclose(file);
+}
+
+}  // namespace hemo
+#endif

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <sstream>
 #include <stdexcept>
@@ -226,7 +227,7 @@ class HemoCellField {
   MeshMetricsView *meshmetric = nullptr;
   CellMechanics *mechanics = nullptr;
   hc_celltype *dev = nullptr;
-  vector<double> vertices; vector<long> triangles;
+  vector<double> vertices; vector<long> triangles; vector<long> innerEdges;
   HemoCellFields *cellFields = nullptr;
   vector<int> desiredOutputVariables;
   ~HemoCellField() { delete materialCfg; delete meshmetric; delete mechanics; if (dev) hcp_celltype_destroy(dev); }
@@ -368,6 +369,7 @@ inline void HemoCellField::create_device_type(int model) {
     for (auto &e : ie->children) { long a, b; if (std::sscanf(e->text.c_str(), "%ld %ld", &a, &b) == 2) { inner.push_back(a); inner.push_back(b); } else pcout << "Inner Edges not read, somethings wrong" << endl; }
   } catch (std::invalid_argument &) {}
   M.inner_edges = inner.empty() ? nullptr : inner.data(); M.n_inner = (int)inner.size() / 2;
+  innerEdges = inner;
   if (constructType != RBC_FROM_SPHERE && constructType != ELLIPSOID_FROM_SPHERE) { hlog << "(HemoCell) (AddCellType) construct type " << constructType << " is not supported by the GPU back end" << endl; std::exit(1); }
   hc_check(hcp_celltype_create(&dev, model, constructType, &Parameters::raw(), &M), "hcp_celltype_create");
   int sz[4]; hcp_celltype_sizes(dev, sz);
@@ -516,10 +518,22 @@ inline void writeCellInfo_CSV(HemoCell &h) {
   CellInformationFunctionals::clear_list();
 }
 
+}  // namespace hemo
+#include "hdf5_output.h"
+namespace hemo {
+
+// core/hemoCell.cpp:221-287: <out>/hdf5/<iter>/ with one file per cell type plus the fluid file, and the CSV summary
 inline void HemoCell::writeOutput() {
-  // HDF5 writers (io/ParticleHdf5IO.cpp, io/FluidHdf5IO.hh) are row (f) rank 2 and not built yet; the CSV
-  // summary is written so that drivers keep producing per-cell data at the same cadence
-  hlog << "(HemoCell) (Output) writing CSV cell summary at " << iter << " (HDF5 output not available in the GPU back end yet)" << endl;
+#ifdef HEMOCELL_WITH_HDF5
+  mkdir((outDir + "/hdf5").c_str(), 0755);
+  const string dir = outDir + "/hdf5/" + zeroPadNumber(iter);
+  mkdir(dir.c_str(), 0755);
+  hlog << "(HemoCell) (Output) writing output at timestep " << iter << " (" << iter * Parameters::dt << " s)" << endl;
+  for (unsigned int t = 0; t < cellfields->size(); t++) writeCellField3D_HDF5(*this, *(*cellfields)[t], dir);
+  writeFluidField_HDF5(*this, dir);
+#else
+  hlog << "(HemoCell) (Output) built without HEMOCELL_WITH_HDF5: only the CSV cell summary is written at " << iter << endl;
+#endif
   writeCellInfo_CSV(*this);
 }
 

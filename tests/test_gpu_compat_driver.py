@@ -10,13 +10,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
+HDF5_INC, HDF5_LIB = "/opt/conda/include", "/opt/conda/lib"
+HAVE_HDF5 = os.path.exists(os.path.join(HDF5_INC, "hdf5.h")) and os.path.exists(os.path.join(HDF5_LIB, "libhdf5_hl.so.100"))
+
+
 def _build(tmp_path, example):
     from hemocell_amd import capi
     out = str(tmp_path / "drv")
     libdir = os.path.dirname(capi.LIB_PATH)
-    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wno-deprecated-declarations", "-I" + os.path.join(ROOT, "include"),
-                           "-I" + os.path.join(ROOT, "hemocell_amd", "compat"), os.path.join(ROOT, example), "-o", out,
-                           "-L" + libdir, "-lhemocell_amd", "-Wl,-rpath," + libdir])
+    cmd = ["g++", "-std=c++14", "-O2", "-Wno-deprecated-declarations", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(ROOT, "hemocell_amd", "compat"), os.path.join(ROOT, example), "-o", out,
+           "-L" + libdir, "-lhemocell_amd", "-Wl,-rpath," + libdir]
+    if HAVE_HDF5:
+        # link the two HDF5 libraries by path and load them from a private directory of symlinks: putting
+        # /opt/conda/lib itself on the search path would also pull in conda's older libstdc++
+        priv = tmp_path / "hdf5lib"
+        priv.mkdir(exist_ok=True)
+        for lib in ("libhdf5.so.103", "libhdf5_hl.so.100", "libz.so.1"):
+            if not (priv / lib).exists():
+                os.symlink(os.path.join(HDF5_LIB, lib), str(priv / lib))
+        cmd += ["-DHEMOCELL_WITH_HDF5", "-I" + HDF5_INC, str(priv / "libhdf5_hl.so.100"), str(priv / "libhdf5.so.103"), "-Wl,-rpath," + str(priv)]
+    subprocess.check_call(cmd)
     return out
 
 
@@ -66,6 +80,32 @@ def test_pipe_driver_validation_bounds(tmp_path, gpu):
         visc, force = float(s[4]), float(s[5])
         assert 1.03 < visc < 3.0, s
         assert force < 4.0, s
+    # ---- output layout (io/ParticleHdf5IO.cpp, io/FluidHdf5IO.hh, io/writeCellInfoCSV.cpp:52)
+    out = os.path.join(ROOT, "examples", "pipe", "tmp_pipe")
+    csv = open(os.path.join(out, "csv", "RBC.000000000400.csv")).read().splitlines()
+    assert csv[0] == "X,Y,Z,area,volume,atomic_block,cellId,baseCellId,velocity_x,velocity_y,velocity_z" and len(csv) == 26
+    if not HAVE_HDF5:
+        return
+    d = os.path.join(out, "hdf5", "000000000400")
+    assert sorted(os.listdir(d)) == ["Fluid.000000000400.p.0.h5", "PLT.000000000400.p.0.h5", "RBC.000000000400.p.0.h5"]
+    hdr = subprocess.run(["/opt/conda/bin/h5dump", "-H", os.path.join(d, "RBC.000000000400.p.0.h5")], capture_output=True, text=True).stdout
+    for name, shape in (("Position", "( 16050, 3 )"), ("Total force", "( 16050, 3 )"), ("Volume force", "( 16050, 3 )"), ("Area force", "( 16050, 3 )"),
+                        ("Bending force", "( 16050, 3 )"), ("Link force", "( 16050, 3 )"), ("Viscous force", "( 16050, 3 )"),
+                        ("Cell Id", "( 16050, 1 )"), ("Vertex Id", "( 16050, 1 )"), ("Triangles", "( 32000, 3 )")):
+        assert 'DATASET "%s"' % name in hdr, name
+        seg = hdr[hdr.index('DATASET "%s"' % name):][:300]
+        assert shape in seg, (name, seg)
+    assert "H5T_IEEE_F32LE" in hdr and "H5T_STD_I32LE" in hdr
+    for attr in ("dx", "dt", "iteration", "processorId", "numberOfProcessors", "numberOfParticles", "numberOfTriangles"):
+        assert 'ATTRIBUTE "%s"' % attr in hdr, attr
+    hp = subprocess.run(["/opt/conda/bin/h5dump", "-H", os.path.join(d, "PLT.000000000400.p.0.h5")], capture_output=True, text=True).stdout
+    assert 'DATASET "InnerLinks"' in hp and "( 105, 2 )" in hp and 'DATASET "Inner link force"' in hp
+    hf = subprocess.run(["/opt/conda/bin/h5dump", "-H", os.path.join(d, "Fluid.000000000400.p.0.h5")], capture_output=True, text=True).stdout
+    for name, c in (("Velocity", 3), ("Force", 3), ("Density", 1), ("Boundary", 1)):
+        seg = hf[hf.index('DATASET "%s"' % name):][:300]
+        assert "( 54, 54, 102, %d )" % c in seg, (name, seg)      # [Nz+2][Ny+2][Nx+2][C]
+    for attr in ("numberOfCells", "subdomainSize", "relativePosition", "dxdydz"):
+        assert 'ATTRIBUTE "%s"' % attr in hf, attr
 
 
 def test_moving_wall_couette_vs_oracle(orc, gpu):

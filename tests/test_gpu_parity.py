@@ -311,3 +311,52 @@ def test_stretch_cell_validation_band(orc, gpu):
     assert 0.98 < info["volume"][0] / info0["volume"][0] <= 1.02
     assert h.cellfields.counts()[1] == 1
     L.destroy()
+
+
+def test_one_cell_shear_config_c1(orc, gpu):
+    """BASELINE config 1, examples/oneCellShear: 40x40x20 box (20x20x10 um at dx 0.5 um), x/y periodic, top and
+    bottom walls moving at -+ (nz-1)*shear/2, one RBC at (9.5,9.5,4.5) um rotated (90,0,0), shear rate 111 1/s,
+    dt 0.5e-7, 1000 iterations with stepMaterialEvery = stepParticleEvery = 1: vertex positions and fluid
+    populations vs the oracle (moving walls: bounce-back + momentum term in both)"""
+    dt = 0.5e-7
+    Po = O.make_params(orc, dt=dt); Pg = gpu.base_parameters(dt=dt)
+    nz = 20; nx = ny = 2 * nz
+    shear = 111.0 * dt; vhalf = (nz - 1) * shear * 0.5     # helper/hemocellInit.hh:82-84
+    mask = np.zeros((nx, ny, nz), np.uint8); mask[:, :, -1] = 3; mask[:, :, 0] = 4
+    Lo, Lg = _both_lattices(orc, gpu, nx, ny, nz, (1, 1, 0), 1.0 / Po.tau, mask)
+    Lo.set_wall_velocity(0, (-vhalf, 0, 0)); Lo.set_wall_velocity(1, (vhalf, 0, 0))
+    Lg.setBoundaryVelocity(3, (-vhalf, 0, 0)); Lg.setBoundaryVelocity(4, (vhalf, 0, 0))
+    Lo.init_equilibrium(); Lg.latticeEquilibrium()
+    Lo.set_threads(8)
+    So = orc.orc_sim_create(Lo.ptr, C.byref(Po)); To = O.make_rbc(orc, Po); orc.orc_sim_add_type(So, To)
+    hg = gpu.HemoCell(Lg, Pg); hg.cellfields.addCellType(gpu.CellType.rbc(Pg), 1)
+    um = 1e-6 / Po.dx
+    assert _add_both(orc, So, hg, 0, (9.5 * um, 9.5 * um, 4.5 * um), (90, 0, 0))
+    for _ in range(50):                                  # warm-up of the cell-free fluid (oneCellShear.cpp:96-101)
+        orc.orc_collide_stream(Lo.ptr)
+    Lg.collideAndStream(50)
+    orc.orc_sim_mechanics(So, 1); hg.cellfields.applyConstitutiveModel(0, True)
+    for _ in range(1000):
+        orc.orc_sim_iterate(So)
+    hg.iterate(1000)
+    p_o, v_o, f_o = _oracle_state(orc, So)
+    p_g = hg.cellfields.positions
+    assert np.abs(p_g - p_o).max() <= 1e-6 * np.abs(p_o).max()
+    assert np.abs(p_g - p_o).max() <= 1e-9, np.abs(p_g - p_o).max()
+    fluid = mask.reshape(-1) == 0
+    assert np.abs(Lg.populations()[fluid] - Lo.f[fluid]).max() <= 1e-6 * np.abs(Lo.f[fluid]).max()
+    # the cell is advected by the shear flow and deforms: it has moved
+    assert np.abs(p_o - _oracle_initial(orc, So, To, (9.5 * um, 9.5 * um, 4.5 * um))).max() > 1e-3
+    Lo.destroy(); Lg.destroy()
+
+
+def _oracle_initial(orc, So, To, centre):
+    """positions right after placement (same placement code path as the run above)"""
+    Po = So.contents.P
+    L = O.OracleLattice(orc, So.contents.L.contents.nx, So.contents.L.contents.ny, So.contents.L.contents.nz, (1, 1, 0), 1.0)
+    S2 = orc.orc_sim_create(L.ptr, C.byref(Po)); orc.orc_sim_add_type(S2, To)
+    c = np.array(centre, dtype=np.float64); a = np.array([90.0, 0, 0]) * (3.14159265358979323846 / 180.0) * -1.0
+    orc.orc_sim_add_cell(S2, 0, O.dptr(c), O.dptr(a), 0.0)
+    p = np.zeros((S2.contents.np, 3)); orc.orc_sim_get(S2, 0, O.dptr(p))
+    orc.orc_sim_destroy(S2); L.destroy()
+    return p

@@ -58,6 +58,8 @@ struct hc_cells {
   int *h_ntag = nullptr;         // pinned host copy of the tag counter
   int *d_ntag = nullptr;         // device counter of tagged cells
   int *d_vert_cell = nullptr;    // [cap] cell slot of every vertex
+  int *d_iscratch[2] = {nullptr, nullptr};   // staged slot lists of the envelope exchange (stream ordered, no sync)
+  size_t iscratch_cap[2] = {0, 0};
   long n_deleted = 0;
 };
 
@@ -244,26 +246,6 @@ __device__ __forceinline__ int stencil_base(const LatView &v, double px, double 
   return 0;
 }
 
-__device__ __forceinline__ void tile_bbox(const LatView &v, int nv, long base, const double *px, const double *py, const double *pz,
-                                          int *s_lo, int *s_hi, Tile &t) {
-  const int tid = threadIdx.x, nth = blockDim.x;
-  if (tid < 3) { s_lo[tid] = 0x7fffffff; s_hi[tid] = -0x7fffffff; }
-  __syncthreads();
-  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
-  for (int i = tid; i < nv; i += nth) {
-    int b[3]; stencil_base(v, px[base + i], py[base + i], pz[base + i], b);
-#pragma unroll
-    for (int a = 0; a < 3; a++) { lo[a] = min(lo[a], b[a]); hi[a] = max(hi[a], b[a] + 1); }
-  }
-#pragma unroll
-  for (int a = 0; a < 3; a++) { atomicMin(&s_lo[a], lo[a]); atomicMax(&s_hi[a], hi[a]); }
-  __syncthreads();
-#pragma unroll
-  for (int a = 0; a < 3; a++) { t.o[a] = s_lo[a]; t.e[a] = s_hi[a] - s_lo[a] + 1; }
-  const long vol = (long)t.e[0] * t.e[1] * t.e[2];
-  t.vol = vol > 0x7fffffff ? 0x7fffffff : (int)vol;
-}
-
 // global lattice element of tile entry i (only meaningful for entries that were admitted by a stencil)
 __device__ __forceinline__ long tile_node(const LatView &v, const Tile &t, int i, int &lx, int &ly, int &lz) {
   const int tz = i % t.e[2], ty = (i / t.e[2]) % t.e[1], tx = i / (t.e[2] * t.e[1]);
@@ -273,11 +255,6 @@ __device__ __forceinline__ long tile_node(const LatView &v, const Tile &t, int i
   if (v.per_z) gz = pmod(gz, v.nz);
   lx = (int)gx; ly = (int)gy; lz = (int)gz;
   return (gx + HALO) * (long)v.plane + gy * v.nz + gz;
-}
-
-__device__ __forceinline__ int tile_index(const Tile &t, const Stencil &s, double px, double py, double pz, const LatView &v) {
-  int b[3]; stencil_base(v, px, py, pz, b);
-  return ((b[0] - t.o[0]) * t.e[1] + (b[1] - t.o[1])) * t.e[2] + (b[2] - t.o[2]);
 }
 
 // compact per-vertex stencil kept in registers across the passes of the cell kernels
@@ -374,7 +351,7 @@ __device__ __forceinline__ bool cell_prologue(const LatView &v, int nv, long bas
 }
 
 __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv, const double *px, const double *py, const double *pz,
-                                                              double *fx, double *fy, double *fz, double *F, int limit_on, double f_limit, int dbg) {
+                                                              double *fx, double *fy, double *fz, double *F, int limit_on, double f_limit) {
   __shared__ double tile[TILE_CAP];
   __shared__ unsigned char mt[TILE_CAP];
   __shared__ int s_red[6 * MAXW];
@@ -423,7 +400,7 @@ __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv,
     __syncthreads();
     for (int i = tid; i < t.vol; i += nth) {
       const double val = tile[i];
-      if (val != 0.0 && !(dbg & 2)) { int lx, ly, lz; unsafeAtomicAdd(&Fc[tile_node(v, t, i, lx, ly, lz)], val); }
+      if (val != 0.0) { int lx, ly, lz; unsafeAtomicAdd(&Fc[tile_node(v, t, i, lx, ly, lz)], val); }
     }
     __syncthreads();
   }
@@ -881,8 +858,6 @@ std::vector<int> flatten(const std::vector<std::array<long, N>> &v) {
 
 }  // namespace
 
-static int g_dbg_spread = 0;   // timing experiments only: 1 = non-atomic flush (WRONG results), 2 = no flush
-extern "C" int hc_debug_spread_mode(int m) { g_dbg_spread = m; return HC_OK; }
 static int g_ibm_per_vertex = 0;  // 1: one thread per vertex with direct global atomics (kept for A/B and as reference)
 extern "C" int hc_debug_ibm_per_vertex(int on) { g_ibm_per_vertex = on; return HC_OK; }
 
@@ -1100,6 +1075,7 @@ int hcp_destroy(hc_cells *C) {
   free_device_arrays(C);
   if (C->h_ntag) hipHostFree(C->h_ntag);
   if (C->d_ntag) hipFree(C->d_ntag);
+  for (int k = 0; k < 2; k++) if (C->d_iscratch[k]) hipFree(C->d_iscratch[k]);
   delete C;
   return HC_OK;
 }
@@ -1262,7 +1238,7 @@ int hcp_spread(hc_cells *C, int force_limit) {
     else
       hipLaunchKernelGGL(ibm_spread_cell_kernel, dim3((unsigned)C->ncells[t]), dim3(nv > 128 ? 256 : 128), 0, hc::stream(), v, nv,
                          (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
-                         C->frc[0] + f, C->frc[1] + f, C->frc[2] + f, C->L->force[C->L->fcur], force_limit, C->P.f_limit, g_dbg_spread);
+                         C->frc[0] + f, C->frc[1] + f, C->frc[2] + f, C->L->force[C->L->fcur], force_limit, C->P.f_limit);
     HC_HIP(hipGetLastError());
   }
   return HC_OK;
@@ -1418,9 +1394,17 @@ static VertArrays vert_arrays(hc_cells *C, int t) {
   for (int d = 0; d < 3; d++) { a.p[d] = C->pos[d] + C->first[t]; a.v[d] = C->vel[d] + C->first[t]; a.f[d] = C->frc[d] + C->first[t]; }
   return a;
 }
-static int upload_ints(int **d, const int *h, int n) {
-  HC_HIP(hipMalloc((void **)d, (size_t)(n > 0 ? n : 1) * sizeof(int)));
-  if (n > 0) HC_HIP(hipMemcpyAsync(*d, h, (size_t)n * sizeof(int), hipMemcpyHostToDevice, hc::stream()));
+// stage a small host int array on the device in a persistent scratch slot; the copy and every later use are
+// ordered on the library stream, so no host synchronisation is needed
+static int stage_ints(hc_cells *C, int which, int **d, const int *h, int n) {
+  if ((size_t)n > C->iscratch_cap[which]) {
+    HC_HIP(hipStreamSynchronize(hc::stream()));
+    if (C->d_iscratch[which]) HC_HIP(hipFree(C->d_iscratch[which]));
+    C->iscratch_cap[which] = (size_t)n * 2 + 256;
+    HC_HIP(hipMalloc((void **)&C->d_iscratch[which], C->iscratch_cap[which] * sizeof(int)));
+  }
+  if (n > 0) HC_HIP(hipMemcpyAsync(C->d_iscratch[which], h, (size_t)n * sizeof(int), hipMemcpyHostToDevice, hc::stream()));
+  *d = C->d_iscratch[which];
   return HC_OK;
 }
 
@@ -1454,12 +1438,9 @@ int hcp_pack_cells(hc_cells *C, int type, const int *slots, int n, double x_shif
   int rc = sync_to_device(C); if (rc != HC_OK) return rc;
   for (int i = 0; i < n; i++) HC_REQUIRE(slots[i] >= 0 && slots[i] < C->ncells[type], "hcp_pack_cells: slot out of range");
   int *d_slots = nullptr;
-  rc = upload_ints(&d_slots, slots, n); if (rc != HC_OK) return rc;
+  rc = stage_ints(C, 0, &d_slots, slots, n); if (rc != HC_OK) return rc;
   hipLaunchKernelGGL(pack_cells_kernel, dim3((unsigned)n), dim3(256), 0, hc::stream(), C->types[type]->host.nv, (const int *)d_slots, vert_arrays(C, type), dev_buf, x_shift);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(hc::stream());
-  hipFree(d_slots);
-  if (e != hipSuccess) return hc::hip_fail(e, "hcp_pack_cells", __FILE__, __LINE__);
+  HC_HIP(hipGetLastError());
   return HC_OK;
 }
 
@@ -1487,14 +1468,11 @@ int hcp_unpack_cells(hc_cells *C, int type, const int *slots, const long *cell_i
     C->nverts += n_new * C->types[type]->host.nv;
   }
   int *d_slots = nullptr, *d_new = nullptr;
-  rc = upload_ints(&d_slots, slots, n); if (rc != HC_OK) return rc;
-  rc = upload_ints(&d_new, is_new, n); if (rc != HC_OK) return rc;
+  rc = stage_ints(C, 0, &d_slots, slots, n); if (rc != HC_OK) return rc;
+  rc = stage_ints(C, 1, &d_new, is_new, n); if (rc != HC_OK) return rc;
   hipLaunchKernelGGL(unpack_cells_kernel, dim3((unsigned)n), dim3(256), 0, hc::stream(), C->types[type]->host.nv, (const int *)d_slots, (const int *)d_new,
                      vert_arrays(C, type), dev_buf, C->L->x0, C->L->nx);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(hc::stream());
-  hipFree(d_slots); hipFree(d_new);
-  if (e != hipSuccess) return hc::hip_fail(e, "hcp_unpack_cells", __FILE__, __LINE__);
+  HC_HIP(hipGetLastError());
   return HC_OK;
 }
 
@@ -1519,13 +1497,10 @@ int hcp_remove_cells(hc_cells *C, int type, const int *slots, int n) {
   C->hids[type].resize((size_t)new_nc);
   if (!src.empty()) {
     int *d_src = nullptr, *d_dst = nullptr;
-    rc = upload_ints(&d_src, src.data(), (int)src.size()); if (rc != HC_OK) return rc;
-    rc = upload_ints(&d_dst, dst.data(), (int)dst.size()); if (rc != HC_OK) return rc;
+    rc = stage_ints(C, 0, &d_src, src.data(), (int)src.size()); if (rc != HC_OK) return rc;
+    rc = stage_ints(C, 1, &d_dst, dst.data(), (int)dst.size()); if (rc != HC_OK) return rc;
     hipLaunchKernelGGL(move_cells_kernel, dim3((unsigned)src.size()), dim3(256), 0, hc::stream(), C->types[type]->host.nv, (const int *)d_src, (const int *)d_dst, vert_arrays(C, type));
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(hc::stream());
-    hipFree(d_src); hipFree(d_dst);
-    if (e != hipSuccess) return hc::hip_fail(e, "hcp_remove_cells", __FILE__, __LINE__);
+    HC_HIP(hipGetLastError());
   }
   C->ncells[type] = new_nc;
   C->nverts -= (long)n * C->types[type]->host.nv;

@@ -38,11 +38,14 @@ class NeighbourComm:
     def exchange(self, send_lo, send_hi, recv_lo, recv_hi):
         """send_lo goes to the low neighbour (which receives it as its recv_hi) and vice versa.
         Returns a callable that completes the transfers into recv_lo / recv_hi."""
-        ops, post = [], []
-        s_lo = self._stage(send_lo) if (self.lo is not None and send_lo is not None) else None
-        s_hi = self._stage(send_hi) if (self.hi is not None and send_hi is not None) else None
-        r_lo = (recv_lo if self.backend == "nccl" else torch.empty(recv_lo.shape, dtype=recv_lo.dtype)) if (self.lo is not None and recv_lo is not None) else None
-        r_hi = (recv_hi if self.backend == "nccl" else torch.empty(recv_hi.shape, dtype=recv_hi.dtype)) if (self.hi is not None and recv_hi is not None) else None
+        ops = []
+
+        def live(t, nb):   # zero-length messages are skipped on both sides (the counts are known to both)
+            return nb is not None and t is not None and t.numel() > 0
+        s_lo = self._stage(send_lo) if live(send_lo, self.lo) else None
+        s_hi = self._stage(send_hi) if live(send_hi, self.hi) else None
+        r_lo = (recv_lo if self.backend == "nccl" else torch.empty(recv_lo.shape, dtype=recv_lo.dtype)) if live(recv_lo, self.lo) else None
+        r_hi = (recv_hi if self.backend == "nccl" else torch.empty(recv_hi.shape, dtype=recv_hi.dtype)) if live(recv_hi, self.hi) else None
         # order matters when lo and hi are the same peer (world == 2): my lo-face message is the peer's
         # hi-halo message, so receives are posted hi first
         if s_lo is not None:

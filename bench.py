@@ -177,6 +177,14 @@ def main():
         launch_nodes = args.nx * args.ny * args.nz
         avg_ms = ms.value / args.steps
         achieved = launch_nodes * bytes_per_node / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM bytes per launch of that kernel from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        # passes, FETCH doubled per the gfx950 note): measured offline on exactly this workload and committed under
+        # profiles/; reported only when the run matches the workload of that measurement
+        traffic, traffic_src = None, None
+        tf = os.path.join(ROOT, "profiles", "r01_c_traffic.json")
+        if os.path.exists(tf) and (args.nx, args.ny, args.nz) == (256, 256, 256) and not args.fluid_only and abs(args.hematocrit - 0.10) < 1e-12:
+            tj = json.load(open(tf))
+            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01_c_traffic.json (rocprofv3 --pmc, %.1f B/node)" % tj["hbm_bytes_per_node"]
         out = {
             "metric": "MLUPS + cell-vertex updates/s, 256^3 pipeflow 10% Hct",
             "value": mlups, "unit": "MLUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -190,7 +198,8 @@ def main():
                        "lattice": [nxg, args.ny, args.nz], "cells": n_cells, "vertices": nverts,
                        "parallelism": "x-slabs x%d, RCCL halo exchange" % world},
             "roofline": {"bound": "hbm", "kernel": "collide_stream_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": launch_nodes * bytes_per_node,
                          "bytes_per_node": bytes_per_node, "nodes_per_launch": launch_nodes, "avg_launch_ms": avg_ms,
                          "launches": n.value, "peak_source": "MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)"},
             "kernel_ms": prof,

@@ -31,6 +31,8 @@ def parse():
     ap.add_argument("--nz", type=int, default=256)
     ap.add_argument("--hematocrit", type=float, default=0.10)
     ap.add_argument("--fluid-only", action="store_true", help="cases/performance_testing style ceiling run")
+    ap.add_argument("--periodic-box", action="store_true",
+                    help="cases/performance_testing geometry: fully periodic box, no walls, tau = 1, body force on all axes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -115,15 +117,21 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     host.init(local_rank)
 
-    P = host.base_parameters()  # examples/pipeflow/config.xml:25-28: dx 5e-7, dt 1e-7, nuP 1.1e-6 -> tau 1.82
+    # examples/pipeflow/config.xml:25-28: dx 5e-7, dt 1e-7, nuP 1.1e-6 -> tau 1.82; performance_testing: dt = -1 -> tau = 1
+    P = host.base_parameters(dt=-1.0) if args.periodic_box else host.base_parameters()
     nxg = args.nx * world
     runner = SlabRunner(nx_local=args.nx, ny=args.ny, nz=args.nz, rank=rank, world=world, P=P,
-                        periodic=(True, False, False), particle_timescale=5, material_timescale=20,
-                        deletion_check_every=1000000)
+                        periodic=(True, True, True) if args.periodic_box else (True, False, False),
+                        particle_timescale=5, material_timescale=20,
+                        deletion_check_every=1000000, fluid_only=args.fluid_only or args.periodic_box)
     mask, R = host.pipe_mask(nxg, args.ny, args.nz)
+    if args.periodic_box:
+        mask[:] = 0
+        args.fluid_only = True
     runner.define_bounce_back(mask)
     runner.lattice.latticeEquilibrium(1.0, (0, 0, 0))
-    runner.lattice.setExternalVector(body_force(args.ny, P.nu_lbm))
+    bf = body_force(args.ny, P.nu_lbm)
+    runner.lattice.setExternalVector((bf[0], bf[0], bf[0]) if args.periodic_box else bf)
     n_cells = 0
     if not args.fluid_only:
         rbc = host.CellType.rbc(P)
@@ -194,7 +202,7 @@ def main():
             "config": {"workload": "examples/pipeflow synthetic: pipe %dx%dx%d (x periodic, analytic cylinder R=%.0f, bounce-back), "
                                    "%d RBC (rbcHighOrderModel, 642 vertices each, target Hct %.2f), tau=%.2f, "
                                    "stepParticleEvery=5, stepMaterialEvery=20%s"
-                                   % (nxg, args.ny, args.nz, R, n_cells, args.hematocrit, P.tau, ", fluid only" if args.fluid_only else ""),
+                                   % (nxg, args.ny, args.nz, R, n_cells, args.hematocrit, P.tau, (", fully periodic box without walls (cases/performance_testing)" if args.periodic_box else ", fluid only") if args.fluid_only else ""),
                        "lattice": [nxg, args.ny, args.nz], "cells": n_cells, "vertices": nverts,
                        "parallelism": "x-slabs x%d, RCCL halo exchange" % world},
             "roofline": {"bound": "hbm", "kernel": "collide_stream_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

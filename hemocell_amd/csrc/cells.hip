@@ -1061,6 +1061,7 @@ int hcp_create(hc_cells **out, hc_lattice *L, const hc_params *P) {
   HC_REQUIRE(out && L && P, "hcp_create: null pointer");
   hc_cells *C = new hc_cells();
   C->L = L; C->P = *P;
+  L->ibm = 1;
   HC_HIP(hipHostMalloc((void **)&C->h_ntag, sizeof(int), hipHostMallocDefault));
   *C->h_ntag = 0;
   HC_HIP(hipMalloc((void **)&C->d_ntag, sizeof(int)));

@@ -56,6 +56,7 @@ struct hc_lattice {
   int cur;               // f[cur] is read by the next collide
   double *force[2];      // [3][npad] IBM force accumulators, ping-pong
   int fcur;              // force[fcur] is the one spread adds to / collide reads
+  int ibm;               // set once membrane cells are bound (hcp_create): collide then reads/zeroes the force buffers
   uint8_t *mask;         // [npad]
   std::vector<uint8_t> hmask;  // host copy (cell placement tests against it)
   double body[3];

@@ -40,6 +40,7 @@ struct LatArgs {
   double bx, by, bz;
   const int *row_z0, *row_cum, *blk_row;
   int nblk;
+  int ibm;               // 0: no membrane cells are bound to this lattice -> the IBM force buffers are not touched
   double wall_u[4][3];   // moving-wall classes 3..6
 };
 
@@ -198,12 +199,13 @@ __global__ __launch_bounds__(256) void collide_stream_kernel(LatArgs a) {
 #undef M
     }
   } else {
-    const double Fx = a.bx + a.Fin[node], Fy = a.by + a.Fin[a.npad + node], Fz = a.bz + a.Fin[2 * a.npad + node];
+    double Fx = a.bx, Fy = a.by, Fz = a.bz;
+    if (a.ibm) { Fx = a.bx + a.Fin[node]; Fy = a.by + a.Fin[a.npad + node]; Fz = a.bz + a.Fin[2 * a.npad + node]; }
     collide_guo(f, Fx, Fy, Fz, a.omega);
   }
 #pragma unroll
   for (int q = 0; q < HC_Q; q++) a.fout[(long)q * a.npad + node] = f[q];
-  a.Fzero[node] = 0.0; a.Fzero[a.npad + node] = 0.0; a.Fzero[2 * a.npad + node] = 0.0;
+  if (a.ibm) { a.Fzero[node] = 0.0; a.Fzero[a.npad + node] = 0.0; a.Fzero[2 * a.npad + node] = 0.0; }
 }
 
 // P(y,i) = mask[y+c_i] ? 0 : feq_i(rho,u): initializeAtEquilibrium in the shifted representation
@@ -321,6 +323,7 @@ LatArgs make_args(const hc_lattice *L) {
   a.per_y = L->periodic[1]; a.per_z = L->periodic[2];
   a.omega = L->omega; a.bx = L->body[0]; a.by = L->body[1]; a.bz = L->body[2];
   a.row_z0 = L->row_z0; a.row_cum = L->row_cum; a.blk_row = L->blk_row; a.nblk = L->nblk;
+  a.ibm = L->ibm;
   for (int c = 0; c < 4; c++) for (int d = 0; d < 3; d++) a.wall_u[c][d] = L->wall_u[c][d];
   return a;
 }
@@ -406,7 +409,7 @@ int hcl_create(hc_lattice **out, int nx, int ny, int nz, const int periodic[3], 
   L->omega = omega;
   L->plane = (size_t)ny * nz;
   L->npad = (size_t)(nx + 2 * HALO) * L->plane;
-  L->cur = 0; L->fcur = 0;
+  L->cur = 0; L->fcur = 0; L->ibm = 0;
   L->body[0] = L->body[1] = L->body[2] = 0.0;
   for (int c = 0; c < 4; c++) for (int d = 0; d < 3; d++) L->wall_u[c][d] = 0.0;
   L->scratch = nullptr; L->scratch_doubles = 0;
@@ -642,9 +645,9 @@ int hcl_halo_pack(hc_lattice *L, int side, int width, double *dev_buf) { return 
 int hcl_halo_unpack(hc_lattice *L, int side, int width, const double *dev_buf) { return halo_copy(L, side, width, (double *)dev_buf, 0); }
 
 double hcl_mlups_bytes_per_node(const hc_lattice *L) {
-  (void)L;
-  // 19 reads + 19 writes of fp64 populations, 3 reads of the IBM force, 3 zeroing writes, 1 mask byte
-  return 19 * 8 * 2 + 3 * 8 * 2 + 1;
+  // 19 reads + 19 writes of fp64 populations and 1 mask byte; with membrane cells bound to the lattice also
+  // 3 reads of the IBM force and 3 zeroing writes (304 B fluid only, 353 B coupled)
+  return 19 * 8 * 2 + 1 + ((L && L->ibm) ? 3 * 8 * 2 : 0);
 }
 
 }  // extern "C"

@@ -95,7 +95,7 @@ class HipEngine:
 
     # ---- cells
     def n_types(self):
-        return len(self.C.types)
+        return len(self.C.types) if self.C is not None else 0
 
     def nv(self, t):
         return self.C.types[t].nv
@@ -136,19 +136,25 @@ class HipEngine:
         return torch.empty(n * self.nv(t) * 9, dtype=torch.float64, device=self.device)
 
     def spread(self):
-        self.C.spreadParticleForce(True)
+        if self.C is not None:
+            self.C.spreadParticleForce(True)
 
     def interpolate(self):
-        self.C.interpolateFluidVelocity()
+        if self.C is not None:
+            self.C.interpolateFluidVelocity()
 
     def advance(self):
-        self.C.advanceParticles(False)
+        if self.C is not None:
+            self.C.advanceParticles(False)
 
     def mechanics(self, it, forced=False):
-        self.C.applyConstitutiveModel(it, forced)
+        if self.C is not None:
+            self.C.applyConstitutiveModel(it, forced)
 
     def owned_vertices(self):
         import ctypes as C
+        if self.C is None:
+            return 0
         n = C.c_long()
         host.check(self.lib.hcp_owned_vertices(self.C.ptr, C.byref(n)))
         return n.value

@@ -15,7 +15,7 @@ from . import host
 
 class SlabRunner:
     def __init__(self, nx_local, ny, nz, rank, world, P, periodic=(True, False, False), particle_timescale=5,
-                 material_timescale=20, deletion_check_every=1, comm=None):
+                 material_timescale=20, deletion_check_every=1, comm=None, fluid_only=False):
         self.rank, self.world = rank, world
         self.nx, self.ny, self.nz = nx_local, ny, nz
         self.nx_global = nx_local * world
@@ -25,10 +25,14 @@ class SlabRunner:
         self.k_p, self.k_m = particle_timescale, material_timescale
         self.lattice = host.Lattice(nx_local, ny, nz, periodic, 1.0 / P.tau, x0=self.x0, nx_global=self.nx_global,
                                     n_slabs=world)
-        self.hemocell = host.HemoCell(self.lattice, P)
-        self.hemocell.setParticleVelocityUpdateTimeScaleSeparation(particle_timescale)
-        self.hemocell.deletion_check_every = deletion_check_every
-        self.cells = self.hemocell.cellfields
+        self.fluid_only = fluid_only   # no membrane cells: the lattice then never touches the IBM force buffers
+        if fluid_only:
+            self.hemocell, self.cells = None, None
+        else:
+            self.hemocell = host.HemoCell(self.lattice, P)
+            self.hemocell.setParticleVelocityUpdateTimeScaleSeparation(particle_timescale)
+            self.hemocell.deletion_check_every = deletion_check_every
+            self.cells = self.hemocell.cellfields
         self.comm = comm
         if world > 1:
             from .exchange import SlabExchange
@@ -52,19 +56,25 @@ class SlabRunner:
         return n
 
     def owned_vertices(self):
+        if self.fluid_only:
+            return 0
         if self.exchange is not None:
             return self.exchange.owned_vertices()
         return self.cells.counts()[0]
 
     def prepare(self):
         """what the drivers do before the loop: forces of the initial configuration"""
-        self.cells.applyConstitutiveModel(0, True)
+        if not self.fluid_only:
+            self.cells.applyConstitutiveModel(0, True)
         if self.exchange is not None:
             self.exchange.prepare()
 
     def run(self, n):
         if self.exchange is None:
-            self.hemocell.iterate(n)
+            if self.fluid_only:
+                self.lattice.collideAndStream(n)
+            else:
+                self.hemocell.iterate(n)
         else:
             self.exchange.run(n)
 

@@ -10,9 +10,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
-NXG, NY, NZ = 96, 34, 34
-CELLS = [((10.0, 16.5, 16.5), (90, 0, 0)), ((46.5, 16.0, 17.0), (80, 20, 10)), ((93.0, 17.0, 16.0), (90, 0, 30)),
-         ((70.0, 12.0, 20.0), (10, 20, 30))]
+NXG, NY, NZ = 144, 34, 34
+CELLS = [((10.0, 16.5, 16.5), (90, 0, 0)), ((46.5, 16.0, 17.0), (80, 20, 10)), ((141.0, 17.0, 16.0), (90, 0, 30)),
+         ((70.0, 12.0, 20.0), (10, 20, 30)), ((96.5, 17.5, 16.0), (90, 10, 0))]
 STEPS, K_P, K_M = 60, 2, 4
 FORCE = (2e-5, 0.0, 0.0)
 
@@ -50,10 +50,10 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_slabs_match_single_domain(tmp_path, gpu):
+@pytest.mark.parametrize("world", [2, 3])
+def test_slabs_match_single_domain(tmp_path, gpu, world):
     import torch.multiprocessing as mp
-    world = 2
-    port = 29500 + os.getpid() % 400
+    port = 29500 + (os.getpid() + 17 * world) % 400
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     res = [torch.load(os.path.join(tmp_path, "r%d.pt" % k), weights_only=False) for k in range(world)]
     ref, mask = _build(0, 1)

@@ -360,3 +360,51 @@ def _oracle_initial(orc, So, To, centre):
     p = np.zeros((S2.contents.np, 3)); orc.orc_sim_get(S2, 0, O.dptr(p))
     orc.orc_sim_destroy(S2); L.destroy()
     return p
+
+
+def test_full_size_properties_config2(gpu):
+    """BASELINE config 2 (pipe 256x128x128, ~5 % Hct, RBC only) at full size, where the oracle is too slow:
+    size-independent properties of the path -- spread conserves the total force, the closed pipe conserves
+    mass, every cell keeps its volume and stays finite, the cell count does not change."""
+    from hemocell_amd.packing import pack_pipe_rbc
+    nx, ny, nz = 256, 128, 128
+    P = gpu.base_parameters()
+    mask, R = gpu.pipe_mask(nx, ny, nz)
+    L = gpu.Lattice(nx, ny, nz, (1, 0, 0), 1.0 / P.tau)
+    L.defineBounceBack(mask); L.latticeEquilibrium()
+    h = gpu.HemoCell(L, P)
+    T = gpu.CellType.rbc(P)
+    h.cellfields.addCellType(T, 20); h.setParticleVelocityUpdateTimeScaleSeparation(5)
+    centres, angles = pack_pipe_rbc(nx, ny, nz, 0.05)
+    n = sum(h.cellfields.addCell(0, c, a, cell_id=i) for i, (c, a) in enumerate(zip(centres, angles)))
+    assert n == len(centres) and n > 150
+    rng = np.random.default_rng(0)
+    pos = h.cellfields.positions
+    h.cellfields.positions = pos + 0.02 * rng.standard_normal(pos.shape)    # N(0, 0.02 lu) as SURVEY 8d prescribes
+    h.cellfields.applyConstitutiveModel(0, True)
+    # (1) spread: sum over the lattice of the IBM force == sum of the (capped) vertex forces
+    h.cellfields.spreadParticleForce(True)
+    F = L.ibm_force(); f = h.cellfields.forces
+    assert np.abs(F.sum(0) - f.sum(0)).max() <= 1e-11 * np.abs(f).sum()
+    assert np.abs(F[mask.reshape(-1) != 0]).max() == 0.0          # nothing lands on boundary nodes
+    check = gpu.capi.check; lib = gpu.capi.lib()
+    check(lib.hcl_zero_ibm_force(L.ptr))
+    # (2) mass conservation over 100 coupled steps in the closed pipe
+    L.setExternalVector((2e-6, 0, 0))
+    # (full-way bounce-back parks the populations that hit a wall on the wall node for one step, so the
+    # conserved quantity is the sum over fluid AND wall nodes)
+    m0 = L.populations().sum()
+    h.iterate(100)
+    pops = L.populations()
+    assert np.isfinite(pops).all()
+    assert abs(pops.sum() - m0) <= 1e-10
+    # (3) cells: none lost, all finite, volume within 1 % and area within 2 % of the undeformed mesh
+    assert h.cellfields.counts()[1] == n and h.cellfields.counts()[2] == 0
+    info = h.cellfields.cell_info(0)
+    t = T.tables()
+    assert np.isfinite(info["volume"]).all()
+    assert np.abs(info["volume"] / t["volume_eq"] - 1).max() < 0.01
+    assert np.abs(info["area"] / (t["area_mean_eq"] * T.nt) - 1).max() < 0.02
+    # (4) flow goes down the pipe: mean x-velocity of the vertices is positive
+    assert h.cellfields.velocities[:, 0].mean() > 0
+    L.destroy()

@@ -312,6 +312,15 @@ __global__ void halo_copy_kernel(HaloArgs h) {
   if (h.to_buf) h.buf[bi] = h.f[li]; else h.f[li] = h.buf[bi];
 }
 
+// clears the 2*HALO halo planes of the three IBM force components
+__global__ void zero_force_halo_kernel(double *F, long npad, int plane, int nx) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= plane) return;
+  const int comp = blockIdx.y / (2 * HALO), w = blockIdx.y % (2 * HALO);
+  const int xp = w < HALO ? w : nx + w;   // padded plane index: 0..HALO-1 and nx+HALO..nx+2*HALO-1
+  F[(long)comp * npad + (long)xp * plane + p] = 0.0;
+}
+
 LatArgs make_args(const hc_lattice *L) {
   LatArgs a;
   a.fin = L->f[L->cur]; a.fout = L->f[1 - L->cur];
@@ -526,15 +535,12 @@ int hcl_collide_stream_part(hc_lattice *L, int part) {
   if (part == 0) rc = launch_collide(L, 0, L->nx);
   else if (part == 1) rc = launch_collide(L, 1, L->nx - 2);
   else { rc = launch_collide(L, 0, 1); if (rc == HC_OK) rc = launch_collide(L, L->nx - 1, 1); }
-  if (rc == HC_OK && L->n_slabs > 1 && part != 1) {
+  if (rc == HC_OK && L->n_slabs > 1 && part != 1 && L->ibm) {
     // the kernel zeroes the other-parity IBM force on the bulk planes; envelope copies of cells also
-    // spread onto the halo planes, which have to be cleared as well
-    double *Fz = L->force[1 - L->fcur];
-    const size_t hb = (size_t)HALO * L->plane * sizeof(double);
-    for (int d = 0; d < 3; d++) {
-      HC_HIP(hipMemsetAsync(Fz + (size_t)d * L->npad, 0, hb, hc::stream()));
-      HC_HIP(hipMemsetAsync(Fz + (size_t)d * L->npad + (size_t)(HALO + L->nx) * L->plane, 0, hb, hc::stream()));
-    }
+    // spread onto the halo planes, which have to be cleared as well (one small launch)
+    hipLaunchKernelGGL(zero_force_halo_kernel, dim3((unsigned)((L->plane + 255) / 256), (unsigned)(2 * HALO * 3), 1), dim3(256), 0, hc::stream(),
+                       L->force[1 - L->fcur], (long)L->npad, (int)L->plane, L->nx);
+    HC_HIP(hipGetLastError());
   }
   return rc;
 }

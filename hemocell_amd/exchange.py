@@ -20,6 +20,7 @@ import torch.distributed as dist
 from . import host
 
 E_SHARE = 4.0   # a cell within this many lattice units of a face is replicated on the neighbour
+MAX_SHARED = 8192   # capacity of the per-face id header of the envelope exchange
 
 
 class NeighbourComm:
@@ -215,23 +216,25 @@ class SlabProtocol:
                 order = np.argsort(ids[slots], kind="stable")
                 slots = slots[order]
                 send[side] = (slots, ids[slots])
-            # phase 1: counts
-            cnt_s = [torch.tensor([len(send[s][0])], dtype=torch.int64, device=self._dev()) for s in (0, 1)]
-            cnt_r = [torch.zeros(1, dtype=torch.int64, device=self._dev()) for _ in (0, 1)]
-            comm.exchange(cnt_s[0], cnt_s[1], cnt_r[0], cnt_r[1])()
-            n_lo = int(cnt_r[0].item()) if comm.lo is not None else 0
-            n_hi = int(cnt_r[1].item()) if comm.hi is not None else 0
-            # phase 2: ids + records
+            # phase 1: one fixed-size header per side: [count, id_0 .. id_{count-1}, padding]
+            assert max(len(send[0][0]), len(send[1][0])) < MAX_SHARED, "more cells cross one slab face than the header holds"
+            hdr_s, hdr_r = [], []
+            for side in (0, 1):
+                hh = np.zeros(MAX_SHARED, dtype=np.int64)
+                hh[0] = len(send[side][0]); hh[1:1 + len(send[side][0])] = send[side][1]
+                hdr_s.append(torch.from_numpy(hh).to(self._dev()))
+                hdr_r.append(torch.zeros(MAX_SHARED, dtype=torch.int64, device=self._dev()))
+            comm.exchange(hdr_s[0], hdr_s[1], hdr_r[0], hdr_r[1])()
+            hr = [hdr_r[0].cpu().numpy() if comm.lo is not None else np.zeros(1, np.int64),
+                  hdr_r[1].cpu().numpy() if comm.hi is not None else np.zeros(1, np.int64)]
+            n_lo, n_hi = int(hr[0][0]), int(hr[1][0])
+            ids_r = [hr[0][1:1 + n_lo], hr[1][1:1 + n_hi]]
+            # phase 2: records
             shift_lo = float(self.nx_global) if (self.periodic_x and comm.rank == 0) else 0.0          # crossing the seam downward
             shift_hi = -float(self.nx_global) if (self.periodic_x and comm.rank == comm.world - 1) else 0.0
-            ids_s = [torch.from_numpy(np.ascontiguousarray(send[s][1])).to(self._dev()) for s in (0, 1)]
-            ids_r = [torch.zeros(n_lo, dtype=torch.int64, device=self._dev()), torch.zeros(n_hi, dtype=torch.int64, device=self._dev())]
             rec_s = [e.pack_cells(t, send[0][0], shift_lo), e.pack_cells(t, send[1][0], shift_hi)]
             rec_r = [e.record_buffer(t, n_lo), e.record_buffer(t, n_hi)]
-            w1 = comm.exchange(ids_s[0], ids_s[1], ids_r[0], ids_r[1])
-            w1()
-            w2 = comm.exchange(rec_s[0], rec_s[1], rec_r[0], rec_r[1])
-            w2()
+            comm.exchange(rec_s[0], rec_s[1], rec_r[0], rec_r[1])()
             self.stats["cells_sent"] += len(send[0][0]) + len(send[1][0])
             # phase 3: merge
             slot_of = {int(i): k for k, i in enumerate(ids)}
@@ -240,7 +243,7 @@ class SlabProtocol:
             for side, cnt in ((0, n_lo), (1, n_hi)):
                 if cnt == 0:
                     continue
-                rid = ids_r[side].cpu().numpy()
+                rid = np.ascontiguousarray(ids_r[side])
                 slots = np.empty(cnt, np.int32); is_new = np.zeros(cnt, np.int32)
                 for k, cid in enumerate(rid):
                     s = slot_of.get(int(cid))

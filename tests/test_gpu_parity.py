@@ -408,3 +408,64 @@ def test_full_size_properties_config2(gpu):
     # (4) flow goes down the pipe: mean x-velocity of the vertices is positive
     assert h.cellfields.velocities[:, 0].mean() > 0
     L.destroy()
+
+
+def test_cell_removed_when_it_reaches_the_wall(orc, gpu):
+    """advanceParticles tags a vertex whose nearest node is a boundary (core/hemoCellParticleField.cpp:571-583);
+    here and in the oracle the whole cell is then removed.  The IBM itself never lets a membrane reach a
+    no-slip wall, so one cell is given a held velocity towards the wall (velocities are only refreshed every
+    stepParticleEvery iterations); a second cell stays.  Both sides delete the same cell at the same iteration
+    and agree afterwards."""
+    nx, ny, nz = 40, 34, 34
+    mask, R = gpu.pipe_mask(nx, ny, nz)
+    Po, Lo, Lg, So, hg = _sim_pair(orc, gpu, nx, ny, nz, (1, 0, 0), mask, k_p=1000)
+    assert _add_both(orc, So, hg, 0, (12.0, 16.5, 16.5), (90, 0, 0))
+    assert _add_both(orc, So, hg, 0, (30.0, 16.5, 25.0), (90, 0, 0))      # 8.5 lu off axis towards +z
+    nv = 642
+    orc.orc_sim_mechanics(So, 1); hg.cellfields.applyConstitutiveModel(0, True)
+    orc.orc_sim_iterate(So); hg.iterate(1)                                # iteration 0 interpolates
+    vel = np.zeros((2 * nv, 3)); vel[nv:, 2] = 0.05
+    orc.orc_sim_set(So, 1, O.dptr(vel)); hg.cellfields.velocities = vel
+    deleted_at = None
+    for it in range(1, 400):
+        orc.orc_sim_iterate(So); hg.iterate(1)
+        assert hg.cellfields.counts()[1] * nv == So.contents.np, it
+        if deleted_at is None and So.contents.np == nv:
+            deleted_at = it
+        if deleted_at is not None and it > deleted_at + 30:
+            break
+    assert deleted_at is not None and 50 < deleted_at < 399
+    assert hg.cellfields.counts() == (nv, 1, 1) and So.contents.cells_deleted == 1
+    p_o, _, _ = _oracle_state(orc, So)
+    assert np.abs(hg.cellfields.positions - p_o).max() <= 1e-9
+    assert hg.cellfields.cell_ids().tolist() == [0]
+    Lo.destroy(); Lg.destroy()
+
+
+def test_long_run_stays_bounded(gpu):
+    """3000 iterations of a 10 % Hct pipe (128x66x66) with the pipeflow cadences: nothing blows up, no cell is
+    lost, cell volumes stay within 2 %, the mean flow is positive and below the cell-free Poiseuille maximum"""
+    from hemocell_amd.packing import pack_pipe_rbc
+    nx, ny, nz = 128, 66, 66
+    P = gpu.base_parameters()
+    mask, R = gpu.pipe_mask(nx, ny, nz)
+    L = gpu.Lattice(nx, ny, nz, (1, 0, 0), 1.0 / P.tau); L.defineBounceBack(mask); L.latticeEquilibrium()
+    h = gpu.HemoCell(L, P); T = gpu.CellType.rbc(P)
+    h.cellfields.addCellType(T, 20); h.setParticleVelocityUpdateTimeScaleSeparation(5)
+    c, a = pack_pipe_rbc(nx, ny, nz, 0.10)
+    n = sum(h.cellfields.addCell(0, cc, aa, cell_id=i) for i, (cc, aa) in enumerate(zip(c, a)))
+    assert n == len(c) and n >= 20
+    h.cellfields.applyConstitutiveModel(0, True)
+    u_max = 0.02                                   # drive hard: ~20x the Re = 0.5 pipeflow case
+    F = 4 * P.nu_lbm * u_max / (R * R)
+    L.setExternalVector((F, 0, 0))
+    h.iterate(3000)
+    info = h.cellfields.cell_info(0)
+    assert h.cellfields.counts()[1] == n
+    assert np.isfinite(h.cellfields.positions).all()
+    assert np.abs(info["volume"] / T.tables()["volume_eq"] - 1).max() < 0.02
+    rho, u = L.rho_u()
+    ux = u[mask.reshape(-1) == 0, 0]
+    assert np.isfinite(ux).all() and 0 < ux.mean() and ux.max() < 1.2 * u_max
+    assert (info["position"][:, 0] > c[:, 0] + 1.0).mean() > 0.8      # the cells were carried downstream
+    L.destroy()

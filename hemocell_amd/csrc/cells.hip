@@ -74,6 +74,7 @@ struct LatView {
   int wrap_x, halo_x;     // single periodic slab: wrap; multi slab: one halo plane is addressable
   int per_y, per_z;
   int nx_global;
+  uint8_t *dirty; uint8_t epoch;   // dirty map of the force buffer spread adds to (see common.h)
 };
 
 LatView make_view(const hc_lattice *L) {
@@ -81,6 +82,7 @@ LatView make_view(const hc_lattice *L) {
   v.mask = L->mask; v.nx = L->nx; v.ny = L->ny; v.nz = L->nz; v.plane = (int)L->plane; v.npad = (long)L->npad;
   v.x0 = L->x0; v.wrap_x = (L->n_slabs == 1 && L->periodic[0]) ? 1 : 0; v.halo_x = L->n_slabs > 1 ? 1 : 0;
   v.per_y = L->periodic[1]; v.per_z = L->periodic[2]; v.nx_global = L->nx_global;
+  v.dirty = L->fdirty[L->fcur]; v.epoch = L->fepoch[L->fcur];
   return v;
 }
 
@@ -162,6 +164,7 @@ __global__ __launch_bounds__(256) void ibm_spread_kernel(LatView v, long n, cons
   for (int k = 0; k < 8; k++) {
     if (s.node[k] < 0) continue;
     // external.data[d] += (force_repulsion[d] + force[d]) * weight  (:857-859); repulsion is 0 (disabled in scope)
+    v.dirty[s.node[k] >> 4] = v.epoch;
     unsafeAtomicAdd(&F[s.node[k]], (0.0 + f0) * s.w[k]);
     unsafeAtomicAdd(&F[v.npad + s.node[k]], (0.0 + f1) * s.w[k]);
     unsafeAtomicAdd(&F[2 * v.npad + s.node[k]], (0.0 + f2) * s.w[k]);
@@ -375,6 +378,7 @@ __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv,
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         if (s.node[k] < 0) continue;
+        v.dirty[s.node[k] >> 4] = v.epoch;
         unsafeAtomicAdd(&F[s.node[k]], f0 * s.w[k]);
         unsafeAtomicAdd(&F[v.npad + s.node[k]], f1 * s.w[k]);
         unsafeAtomicAdd(&F[2 * v.npad + s.node[k]], f2 * s.w[k]);
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv,
     __syncthreads();
     for (int i = tid; i < t.vol; i += nth) {
       const double val = tile[i];
-      if (val != 0.0) { int lx, ly, lz; unsafeAtomicAdd(&Fc[tile_node(v, t, i, lx, ly, lz)], val); }
+      if (val != 0.0) { int lx, ly, lz; const long node = tile_node(v, t, i, lx, ly, lz); v.dirty[node >> 4] = v.epoch; unsafeAtomicAdd(&Fc[node], val); }
     }
     __syncthreads();
   }

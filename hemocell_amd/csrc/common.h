@@ -57,6 +57,12 @@ struct hc_lattice {
   double *force[2];      // [3][npad] IBM force accumulators, ping-pong
   int fcur;              // force[fcur] is the one spread adds to / collide reads
   int ibm;               // set once membrane cells are bound (hcp_create): collide then reads/zeroes the force buffers
+  // dirty map of the IBM force buffers: one byte per group of 16 consecutive nodes (one 128-byte line of a
+  // force component) holding the epoch in which spread last touched the group.  The collide kernel reads /
+  // zeroes a group only when its byte equals the buffer's current epoch, so untouched lines cost no traffic.
+  // Epochs are never cleared (no races); an aliased stale epoch only causes a harmless extra read / zeroing.
+  uint8_t *fdirty[2];
+  uint8_t fepoch[2];
   uint8_t *mask;         // [npad]
   std::vector<uint8_t> hmask;  // host copy (cell placement tests against it)
   double body[3];

@@ -41,6 +41,7 @@ struct LatArgs {
   const int *row_z0, *row_cum, *blk_row;
   int nblk;
   int ibm;               // 0: no membrane cells are bound to this lattice -> the IBM force buffers are not touched
+  const uint8_t *dirty_in, *dirty_zero; uint8_t epoch_in, epoch_zero;
   double wall_u[4][3];   // moving-wall classes 3..6
 };
 
@@ -200,12 +201,14 @@ __global__ __launch_bounds__(256) void collide_stream_kernel(LatArgs a) {
     }
   } else {
     double Fx = a.bx, Fy = a.by, Fz = a.bz;
-    if (a.ibm) { Fx = a.bx + a.Fin[node]; Fy = a.by + a.Fin[a.npad + node]; Fz = a.bz + a.Fin[2 * a.npad + node]; }
+    if (a.ibm && a.dirty_in[node >> 4] == a.epoch_in) {   // x + 0.0 == x, so skipping untouched groups changes no bits
+      Fx = a.bx + a.Fin[node]; Fy = a.by + a.Fin[a.npad + node]; Fz = a.bz + a.Fin[2 * a.npad + node];
+    }
     collide_guo(f, Fx, Fy, Fz, a.omega);
   }
 #pragma unroll
   for (int q = 0; q < HC_Q; q++) a.fout[(long)q * a.npad + node] = f[q];
-  if (a.ibm) { a.Fzero[node] = 0.0; a.Fzero[a.npad + node] = 0.0; a.Fzero[2 * a.npad + node] = 0.0; }
+  if (a.ibm && a.dirty_zero[node >> 4] == a.epoch_zero) { a.Fzero[node] = 0.0; a.Fzero[a.npad + node] = 0.0; a.Fzero[2 * a.npad + node] = 0.0; }
 }
 
 // P(y,i) = mask[y+c_i] ? 0 : feq_i(rho,u): initializeAtEquilibrium in the shifted representation
@@ -333,6 +336,7 @@ LatArgs make_args(const hc_lattice *L) {
   a.omega = L->omega; a.bx = L->body[0]; a.by = L->body[1]; a.bz = L->body[2];
   a.row_z0 = L->row_z0; a.row_cum = L->row_cum; a.blk_row = L->blk_row; a.nblk = L->nblk;
   a.ibm = L->ibm;
+  a.dirty_in = L->fdirty[L->fcur]; a.dirty_zero = L->fdirty[1 - L->fcur]; a.epoch_in = L->fepoch[L->fcur]; a.epoch_zero = L->fepoch[1 - L->fcur];
   for (int c = 0; c < 4; c++) for (int d = 0; d < 3; d++) a.wall_u[c][d] = L->wall_u[c][d];
   return a;
 }
@@ -422,7 +426,7 @@ int hcl_create(hc_lattice **out, int nx, int ny, int nz, const int periodic[3], 
   L->body[0] = L->body[1] = L->body[2] = 0.0;
   for (int c = 0; c < 4; c++) for (int d = 0; d < 3; d++) L->wall_u[c][d] = 0.0;
   L->scratch = nullptr; L->scratch_doubles = 0;
-  L->f[0] = L->f[1] = L->force[0] = L->force[1] = nullptr; L->mask = nullptr;
+  L->f[0] = L->f[1] = L->force[0] = L->force[1] = nullptr; L->mask = nullptr; L->fdirty[0] = L->fdirty[1] = nullptr;
   for (int k = 0; k < 2; k++) {
     HC_HIP(hipMalloc((void **)&L->f[k], L->npad * HC_Q * sizeof(double)));
     HC_HIP(hipMemsetAsync(L->f[k], 0, L->npad * HC_Q * sizeof(double), hc::stream()));
@@ -431,6 +435,11 @@ int hcl_create(hc_lattice **out, int nx, int ny, int nz, const int periodic[3], 
   }
   HC_HIP(hipMalloc((void **)&L->mask, L->npad));
   HC_HIP(hipMemsetAsync(L->mask, 0, L->npad, hc::stream()));
+  for (int k = 0; k < 2; k++) {
+    HC_HIP(hipMalloc((void **)&L->fdirty[k], L->npad / 16 + 1));
+    HC_HIP(hipMemsetAsync(L->fdirty[k], 0, L->npad / 16 + 1, hc::stream()));
+    L->fepoch[k] = 1;
+  }
   L->hmask.assign(L->npad, 0);
   L->row_z0 = L->row_cum = L->blk_row = nullptr;
   { int rc = rebuild_active_map(L); if (rc != HC_OK) return rc; }
@@ -442,7 +451,7 @@ int hcl_create(hc_lattice **out, int nx, int ny, int nz, const int periodic[3], 
 int hcl_destroy(hc_lattice *L) {
   if (!L) return HC_OK;
   hipStreamSynchronize(hc::stream());
-  for (int k = 0; k < 2; k++) { if (L->f[k]) hipFree(L->f[k]); if (L->force[k]) hipFree(L->force[k]); }
+  for (int k = 0; k < 2; k++) { if (L->f[k]) hipFree(L->f[k]); if (L->force[k]) hipFree(L->force[k]); if (L->fdirty[k]) hipFree(L->fdirty[k]); }
   if (L->mask) hipFree(L->mask);
   if (L->scratch) hipFree(L->scratch);
   if (L->row_z0) hipFree(L->row_z0);
@@ -548,6 +557,7 @@ int hcl_collide_stream_part(hc_lattice *L, int part) {
 int hcl_step_end(hc_lattice *L) {
   HC_REQUIRE(L, "hcl_step_end: null lattice");
   L->cur ^= 1; L->fcur ^= 1;
+  L->fepoch[L->fcur] = (uint8_t)(L->fepoch[L->fcur] % 255 + 1);   // the buffer spread will add to next gets a fresh epoch (1..255)
   return HC_OK;
 }
 

@@ -49,12 +49,15 @@ int main(int argc, char *argv[]) {
   hemocell.setOutputs("PLT", outputs);
   hemocell.setFluidOutputs({OUTPUT_VELOCITY, OUTPUT_DENSITY, OUTPUT_FORCE, OUTPUT_BOUNDARY});
   hemocell.setSystemPeriodicity(0, true);
-  hemocell.loadParticles();
+  if (not cfg->checkpointed) hemocell.loadParticles();
+  else hemocell.loadCheckPoint();       // started with <out>/checkpoint/checkpoint.xml as configuration
 
   setExternalVector(*hemocell.lattice, hemocell.lattice->getBoundingBox(), DESCRIPTOR<T>::ExternalField::forceBeginsAt,
                     plb::Array<T, DESCRIPTOR<T>::d>(drivingForce, 0.0, 0.0));
-  for (plint i = 0; i < (*cfg)["parameters"]["warmup"].read<plint>(); ++i) hemocell.lattice->collideAndStream();
+  if (hemocell.iter == 0)
+    for (plint i = 0; i < (*cfg)["parameters"]["warmup"].read<plint>(); ++i) hemocell.lattice->collideAndStream();
 
+  const unsigned tcheckpoint = (*cfg)["sim"]["tcheckpoint"].read<unsigned int>();
   const unsigned tmax = (*cfg)["sim"]["tmax"].read<unsigned int>(), tmeas = (*cfg)["sim"]["tmeas"].read<unsigned int>();
   while (hemocell.iter < tmax) {
     hemocell.iterate();
@@ -67,6 +70,7 @@ int main(int argc, char *argv[]) {
                   CellInformationFunctionals::getNumberOfCellsFromType(&hemocell, "RBC"), CellInformationFunctionals::getNumberOfCellsFromType(&hemocell, "PLT"),
                   (param::u_lbm_max * 0.5) / finfo.avg, pinfo.avg * param::df * 1.0e12);
     }
+    if (hemocell.iter % tcheckpoint == 0) hemocell.saveCheckPoint();
   }
   hemocell.writeOutput();   // <out>/hdf5/<iter>/{RBC,PLT,Fluid}.<iter>.p.0.h5 + <out>/csv
   return 0;

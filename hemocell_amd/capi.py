@@ -72,6 +72,7 @@ SIGNATURES = {
     "hcp_destroy": (C.c_int, [VP]),
     "hcp_add_type": (C.c_int, [VP, VP, C.c_int, c_int_p]),
     "hcp_add_cell": (C.c_int, [VP, C.c_int, C.c_long, c_double_p, c_double_p, C.c_double, c_int_p]),
+    "hcp_add_cell_unchecked": (C.c_int, [VP, C.c_int, C.c_long, c_double_p, c_double_p]),
     "hcp_counts": (C.c_int, [VP, c_long_p, c_long_p, c_long_p]),
     "hcp_type_range": (C.c_int, [VP, C.c_int, c_long_p, c_long_p]),
     "hcp_download": (C.c_int, [VP, C.c_int, c_double_p]),

@@ -294,6 +294,7 @@ class HemoCell {
   HemoCell(char *configFileName, int, char *[], MPIHandle) {
     hc_check(hc_init(0), "hc_init");       // replaces plb::plbInit (core/hemoCell.cpp:80-86)
     cfg = new Config(configFileName);
+    configFile = configFileName;
     try { outDir = (*cfg)["parameters"]["outputDirectory"].read<string>(); } catch (std::invalid_argument &) { outDir = "tmp"; }
     mkdir(outDir.c_str(), 0755); mkdir((outDir + "/log").c_str(), 0755); mkdir((outDir + "/csv").c_str(), 0755);
     hlog_instance().file.open((outDir + "/log/logfile").c_str());
@@ -330,8 +331,8 @@ class HemoCell {
   void setSystemPeriodicity(unsigned int axis, bool bePeriodic) { lattice->periodicity().toggle((int)axis, bePeriodic); }
   void setSystemPeriodicityLimit(unsigned int, int) {}
   void loadParticles();
-  void loadCheckPoint() { hlog << "(HemoCell) checkpoints use Palabos' own binary format and are not supported by the GPU back end" << endl; std::exit(1); }
-  void saveCheckPoint() { hlog << "(HemoCell) (saveCheckPoint) skipped: not supported by the GPU back end yet" << endl; }
+  void loadCheckPoint();
+  void saveCheckPoint();
   void writeOutput();
   void iterate() {
     hc_cells *c = cellfields->device();
@@ -347,7 +348,7 @@ class HemoCell {
   HemoCellFields *cellfields = nullptr;
   unsigned int iter = 0;
   void *preInlet = nullptr;
-  string outDir;
+  string outDir, configFile;
   vector<int> fluidOutputs;
 };
 
@@ -417,6 +418,73 @@ inline void HemoCell::loadParticles() {
   }
   long it = iter;   // forces of the initial configuration, as the first applyConstitutiveModel would give them
   hc_check(hcp_mechanics(c, it, 1), "hcp_mechanics");
+}
+
+// ------------------------------------------------------------------ checkpoint / resume (core/hemoCellFields.cpp:240-319)
+// The reference writes Palabos' own parallelIO dumps plus checkpoint.xml (a copy of the config under a <Checkpoint>
+// root with the iteration); the binary format here is this back end's own: populations in the reference node
+// order, then per type the cell ids and the vertex position / velocity / force arrays.
+inline void HemoCell::saveCheckPoint() {
+  const string dir = outDir + "/checkpoint";
+  mkdir(dir.c_str(), 0755);
+  rename((dir + "/checkpoint.bin").c_str(), (dir + "/checkpoint.bin.old").c_str());   // :283-290 keeps the previous one
+  rename((dir + "/checkpoint.xml").c_str(), (dir + "/checkpoint.xml.old").c_str());
+  hc_lattice *d = lattice->device(); hc_cells *c = cellfields->device();
+  const size_t n = (size_t)lattice->nx * lattice->ny * lattice->nz;
+  vector<double> f(n * HC_Q);
+  hc_check(hcl_download_populations(d, f.data()), "hcl_download_populations");
+  std::ofstream o((dir + "/checkpoint.bin").c_str(), std::ios::binary);
+  const long hdr[6] = {0x48434b50, (long)iter, lattice->nx, lattice->ny, lattice->nz, (long)cellfields->size()};
+  o.write((const char *)hdr, sizeof(hdr));
+  o.write((const char *)f.data(), (std::streamsize)(f.size() * sizeof(double)));
+  long nvt = 0, nct = 0; hcp_counts(c, &nvt, &nct, nullptr);
+  vector<long> ids((size_t)nct); if (nct) hcp_download_cell_ids(c, ids.data());
+  o.write((const char *)&nct, sizeof(long)); o.write((const char *)ids.data(), (std::streamsize)(ids.size() * sizeof(long)));
+  for (unsigned int t = 0; t < cellfields->size(); t++) { long fv, nc; hcp_type_range(c, (int)t, &fv, &nc); o.write((const char *)&nc, sizeof(long)); }
+  for (int what = 0; what < 3; what++) {
+    vector<double> a(3 * (size_t)nvt); if (nvt) hc_check(hcp_download(c, what, a.data()), "hcp_download");
+    o.write((const char *)a.data(), (std::streamsize)(a.size() * sizeof(double)));
+  }
+  std::ofstream x((dir + "/checkpoint.xml").c_str());
+  x << "<?xml version=\"1.0\" ?>\n<Checkpoint>\n<General><Iteration>" << iter << "</Iteration><OutDirectory>" << outDir << "</OutDirectory></General>\n";
+  std::ifstream cfgin(configFile.c_str()); string line; bool first = true;
+  while (std::getline(cfgin, line)) { if (first && line.find("<?xml") != string::npos) { first = false; continue; } x << line << "\n"; }
+  x << "</Checkpoint>\n";
+  hlog << "(HemoCell) (saveCheckPoint) saved iteration " << iter << " to " << dir << endl;
+}
+
+inline void HemoCell::loadCheckPoint() {
+  const string dir = outDir + "/checkpoint";
+  std::ifstream in((dir + "/checkpoint.bin").c_str(), std::ios::binary);
+  if (!in.is_open()) { hlog << "(HemoCell) (loadCheckPoint) " << dir << "/checkpoint.bin not found" << endl; std::exit(1); }
+  long hdr[6]; in.read((char *)hdr, sizeof(hdr));
+  if (hdr[0] != 0x48434b50 || hdr[2] != lattice->nx || hdr[3] != lattice->ny || hdr[4] != lattice->nz || hdr[5] != (long)cellfields->size()) {
+    hlog << "(HemoCell) (loadCheckPoint) checkpoint does not match this case (lattice size / cell types)" << endl; std::exit(1);
+  }
+  hc_lattice *d = lattice->device(); hc_cells *c = cellfields->device();
+  const size_t n = (size_t)lattice->nx * lattice->ny * lattice->nz;
+  vector<double> f(n * HC_Q);
+  in.read((char *)f.data(), (std::streamsize)(f.size() * sizeof(double)));
+  hc_check(hcl_upload_populations(d, f.data()), "hcl_upload_populations");
+  long nct = 0; in.read((char *)&nct, sizeof(long));
+  vector<long> ids((size_t)nct); in.read((char *)ids.data(), (std::streamsize)(ids.size() * sizeof(long)));
+  vector<long> per_type(cellfields->size()); for (auto &v : per_type) in.read((char *)&v, sizeof(long));
+  // recreate the cells (placement is overwritten by the stored state right below)
+  long k = 0, nvt = 0;
+  for (unsigned int t = 0; t < cellfields->size(); t++)
+    for (long i = 0; i < per_type[t]; i++, k++) {
+      const double centre[3] = {lattice->nx * 0.5, lattice->ny * 0.5, lattice->nz * 0.5}, ang[3] = {0, 0, 0}; int placed = 0;
+      hc_check(hcp_add_cell_unchecked(c, (int)t, ids[(size_t)k], centre, ang), "hcp_add_cell_unchecked");
+      (void)placed; nvt += (*cellfields)[t]->numVertex;
+    }
+  cellfields->number_of_cells = (int)nct;
+  for (int what = 0; what < 3; what++) {
+    vector<double> a(3 * (size_t)nvt); in.read((char *)a.data(), (std::streamsize)(a.size() * sizeof(double)));
+    if (nvt) hc_check(hcp_upload(c, what, a.data()), "hcp_upload");
+  }
+  iter = (unsigned int)hdr[1];
+  lattice->mark_stepped();
+  hlog << "(HemoCell) (loadCheckPoint) resumed at iteration " << iter << endl;
 }
 
 // ------------------------------------------------------------------ helper/cellInfo.h

@@ -1148,6 +1148,19 @@ int hcp_add_cell(hc_cells *C, int type, long cell_id, const double centre_lu[3],
   return HC_OK;
 }
 
+int hcp_add_cell_unchecked(hc_cells *C, int type, long cell_id, const double centre_lu[3], const double angles[3]) {
+  HC_REQUIRE(C && centre_lu && angles, "hcp_add_cell_unchecked: null pointer");
+  HC_REQUIRE(type >= 0 && type < C->ntypes, "hcp_add_cell_unchecked: unknown cell type");
+  int rc = sync_to_host(C); if (rc != HC_OK) return rc;
+  const CellTables &T = C->types[type]->host;
+  (void)angles;
+  for (int i = 0; i < T.nv; i++)
+    for (int d = 0; d < 3; d++) { C->hpos[type].push_back(centre_lu[d] + T.vertices[i][d]); C->hvel[type].push_back(0.0); C->hfrc[type].push_back(0.0); }
+  C->hids[type].push_back(cell_id);
+  C->host_dirty = true;
+  return HC_OK;
+}
+
 int hcp_counts(const hc_cells *C, long *n_vertices, long *n_cells, long *n_deleted) {
   HC_REQUIRE(C, "hcp_counts: null pointer");
   long nv = 0, nc = 0;

@@ -143,6 +143,9 @@ int hcp_add_type(hc_cells *C, hc_celltype *T, int material_timescale /* setMater
  * within min_dist_um of a boundary node (:139-164) and the cell is dropped. */
 int hcp_add_cell(hc_cells *C, int type, long cell_id, const double centre_lu[3], const double angles[3],
                  double min_dist_um, int *placed);
+/* slot for a cell whose state is restored afterwards with hcp_upload (checkpoint resume,
+ * core/hemoCellFields.cpp:240-275): undeformed mesh at centre_lu, no wall test */
+int hcp_add_cell_unchecked(hc_cells *C, int type, long cell_id, const double centre_lu[3], const double angles[3]);
 int hcp_counts(const hc_cells *C, long *n_vertices, long *n_cells, long *n_deleted);
 int hcp_type_range(const hc_cells *C, int type, long *first_vertex, long *n_cells);
 /* serializeValues_t fields as [n][3] arrays in cell-major order; what: 0 position 1 velocity 2 force */

@@ -80,6 +80,16 @@ def test_pipe_driver_validation_bounds(tmp_path, gpu):
         visc, force = float(s[4]), float(s[5])
         assert 1.03 < visc < 3.0, s
         assert force < 4.0, s
+    # ---- checkpoint / resume (core/hemoCellFields.cpp:240-319): restart from the dump written at iteration 200 with
+    # checkpoint.xml as the configuration, like the reference; the continuation reproduces the remaining lines exactly
+    ck = os.path.join(ROOT, "examples", "pipe", "tmp_pipe", "checkpoint")
+    assert os.path.exists(os.path.join(ck, "checkpoint.bin.old")) and os.path.exists(os.path.join(ck, "checkpoint.xml.old"))
+    os.replace(os.path.join(ck, "checkpoint.bin.old"), os.path.join(ck, "checkpoint.bin"))     # the iteration-200 dump
+    os.replace(os.path.join(ck, "checkpoint.xml.old"), os.path.join(ck, "checkpoint.xml"))
+    r2 = subprocess.run([exe, "tmp_pipe/checkpoint/checkpoint.xml"], cwd=os.path.join(ROOT, "examples", "pipe"), capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
+    stats2 = [l for l in r2.stdout.splitlines() if l.startswith("STAT")]
+    assert stats2 == [l for l in r.stdout.splitlines() if l.startswith("STAT")][2:], (stats2, stats)
     # ---- output layout (io/ParticleHdf5IO.cpp, io/FluidHdf5IO.hh, io/writeCellInfoCSV.cpp:52)
     out = os.path.join(ROOT, "examples", "pipe", "tmp_pipe")
     csv = open(os.path.join(out, "csv", "RBC.000000000400.csv")).read().splitlines()

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 NXG, NY, NZ = 144, 34, 34
 CELLS = [((10.0, 16.5, 16.5), (90, 0, 0)), ((46.5, 16.0, 17.0), (80, 20, 10)), ((141.0, 17.0, 16.0), (90, 0, 30)),
          ((70.0, 12.0, 20.0), (10, 20, 30)), ((96.5, 17.5, 16.0), (90, 10, 0))]
+PLTS = [((47.0, 12.0, 21.0), (20, 40, 10)), ((120.0, 20.0, 13.0), (0, 0, 0)), ((143.5, 15.0, 21.5), (70, 0, 30))]   # platelets, two at faces
 STEPS, K_P, K_M = 60, 2, 4
 FORCE = (2e-5, 0.0, 0.0)
 
@@ -28,7 +29,13 @@ def _build(rank, world):
     r.lattice.latticeEquilibrium(1.0, (0, 0, 0))
     r.lattice.setExternalVector(FORCE)
     r.add_cell_type(host.CellType.rbc(P))
+    r.add_cell_type(host.CellType.plt(P))
     r.load_cells(0, [np.array(c) for c, _ in CELLS], [np.array(a) for _, a in CELLS])
+    if world > 1:
+        r.exchange.load_cells(1, [np.array(c) for c, _ in PLTS], [np.array(a) for _, a in PLTS], radius=3.0)
+    else:
+        for i, (c, a) in enumerate(PLTS):
+            assert r.cells.addCell(1, np.array(c), np.array(a), cell_id=i)
     r.prepare()
     return r, mask
 
@@ -44,7 +51,9 @@ def _worker(rank, world, port, out):
     r, _ = _build(rank, world)
     r.run(STEPS)
     cid, vid, pos = r.owned_vertex_table(0)
-    torch.save(dict(f=r.populations(), cid=cid, vid=vid, pos=pos, held=r.cells.counts()[1], stats=r.exchange.protocol.stats),
+    pcid, pvid, ppos = r.owned_vertex_table(1)
+    torch.save(dict(f=r.populations(), cid=cid, vid=vid, pos=pos, pcid=pcid, pvid=pvid, ppos=ppos, held=r.cells.counts()[1],
+                    stats=r.exchange.protocol.stats),
                os.path.join(out, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -63,13 +72,15 @@ def test_slabs_match_single_domain(tmp_path, gpu, world):
     fluid = (mask.reshape(NXG, NY * NZ) == 0)
     err_f = np.abs(f_two - f_ref)[fluid].max()
     assert err_f <= 1e-12, err_f
-    p_ref = ref.cells.positions.reshape(len(CELLS), -1, 3)
-    seen = np.zeros(p_ref.shape[:2], dtype=int)
-    for r in res:
-        for c, v, p in zip(r["cid"], r["vid"], r["pos"]):
-            d = p - p_ref[c, v]
-            d[0] = (d[0] + NXG / 2) % NXG - NXG / 2
-            assert np.abs(d).max() <= 1e-10, (c, v, d)
-            seen[c, v] += 1
-    assert (seen == 1).all()          # every vertex owned by exactly one rank
-    assert sum(r["held"] for r in res) > len(CELLS)   # cells near the faces are replicated
+    allpos = ref.cells.positions
+    nrbc = len(CELLS) * 642
+    for key, p_ref in ((("cid", "vid", "pos"), allpos[:nrbc].reshape(len(CELLS), -1, 3)), (("pcid", "pvid", "ppos"), allpos[nrbc:].reshape(len(PLTS), -1, 3))):
+        seen = np.zeros(p_ref.shape[:2], dtype=int)
+        for r in res:
+            for c, v, p in zip(r[key[0]], r[key[1]], r[key[2]]):
+                d = p - p_ref[c, v]
+                d[0] = (d[0] + NXG / 2) % NXG - NXG / 2
+                assert np.abs(d).max() <= 1e-10, (key, c, v, d)
+                seen[c, v] += 1
+        assert (seen == 1).all()          # every vertex owned by exactly one rank
+    assert sum(r["held"] for r in res) > len(CELLS) + len(PLTS)   # cells near the faces are replicated

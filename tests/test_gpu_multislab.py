@@ -12,10 +12,13 @@ pytestmark = pytest.mark.gpu
 
 NXG, NY, NZ = 144, 34, 34
 CELLS = [((10.0, 16.5, 16.5), (90, 0, 0)), ((46.5, 16.0, 17.0), (80, 20, 10)), ((141.0, 17.0, 16.0), (90, 0, 30)),
-         ((70.0, 12.0, 20.0), (10, 20, 30)), ((96.5, 17.5, 16.0), (90, 10, 0))]
+         ((70.0, 12.0, 20.0), (10, 20, 30)), ((96.5, 17.5, 16.0), (90, 10, 0)), ((57.5, 21.0, 14.0), (90, 0, 0))]
 PLTS = [((47.0, 12.0, 21.0), (20, 40, 10)), ((120.0, 20.0, 13.0), (0, 0, 0)), ((143.5, 15.0, 21.5), (70, 0, 30))]   # platelets, two at faces
-STEPS, K_P, K_M = 60, 2, 4
-FORCE = (2e-5, 0.0, 0.0)
+# fast flow: the cells travel ~6 lu in 250 iterations, so envelope copies are created and dropped at the faces.
+# (Beyond ~300 iterations this strongly driven case amplifies a 1e-13 perturbation to 1e-5 even on a single
+# domain, so longer runs cannot be compared position by position.)
+STEPS, K_P, K_M = 250, 2, 4
+FORCE = (3e-4, 0.0, 0.0)
 
 
 def _build(rank, world):
@@ -59,6 +62,14 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _initial_x():
+    from hemocell_amd import host
+    r0, _ = _build(0, 1)
+    x = r0.cells.positions[:, 0].copy()
+    r0.lattice.destroy()
+    return x
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_slabs_match_single_domain(tmp_path, gpu, world):
     import torch.multiprocessing as mp
@@ -71,7 +82,7 @@ def test_slabs_match_single_domain(tmp_path, gpu, world):
     f_two = np.concatenate([r["f"].reshape(NXG // world, NY * NZ, 19) for r in res], axis=0)
     fluid = (mask.reshape(NXG, NY * NZ) == 0)
     err_f = np.abs(f_two - f_ref)[fluid].max()
-    assert err_f <= 1e-12, err_f
+    assert err_f <= 1e-10, err_f
     allpos = ref.cells.positions
     nrbc = len(CELLS) * 642
     for key, p_ref in ((("cid", "vid", "pos"), allpos[:nrbc].reshape(len(CELLS), -1, 3)), (("pcid", "pvid", "ppos"), allpos[nrbc:].reshape(len(PLTS), -1, 3))):
@@ -80,7 +91,13 @@ def test_slabs_match_single_domain(tmp_path, gpu, world):
             for c, v, p in zip(r[key[0]], r[key[1]], r[key[2]]):
                 d = p - p_ref[c, v]
                 d[0] = (d[0] + NXG / 2) % NXG - NXG / 2
-                assert np.abs(d).max() <= 1e-10, (key, c, v, d)
+                assert np.abs(d).max() <= 1e-8, (key, c, v, d)
                 seen[c, v] += 1
         assert (seen == 1).all()          # every vertex owned by exactly one rank
     assert sum(r["held"] for r in res) > len(CELLS) + len(PLTS)   # cells near the faces are replicated
+    n_new, n_drop = sum(r["stats"]["cells_new"] for r in res), sum(r["stats"]["cells_dropped"] for r in res)
+    assert n_new + n_drop > 0                      # envelope copies changed hands during the run
+    if world == 2:
+        assert n_new > 0 and n_drop > 0            # both a fresh copy and a dropped copy (faces at x = 72 and the seam)
+    travelled = np.abs(allpos[:, 0] - _initial_x()).max()
+    assert travelled > 5.0, travelled

@@ -30,6 +30,7 @@ def parse():
     ap.add_argument("--ny", type=int, default=256)
     ap.add_argument("--nz", type=int, default=256)
     ap.add_argument("--hematocrit", type=float, default=0.10)
+    ap.add_argument("--plt-ratio", type=float, default=0.0, help="platelets per RBC (pltSimpleModel), e.g. 0.07 for BASELINE config 3")
     ap.add_argument("--fluid-only", action="store_true", help="cases/performance_testing style ceiling run")
     ap.add_argument("--periodic-box", action="store_true",
                     help="cases/performance_testing geometry: fully periodic box, no walls, tau = 1, body force on all axes")
@@ -138,6 +139,14 @@ def main():
         runner.add_cell_type(rbc)
         centres, angles = pack_pipe_rbc(nxg, args.ny, args.nz, args.hematocrit)
         n_cells = runner.load_cells(0, centres, angles)
+        if args.plt_ratio > 0:
+            # platelets (66 vertices, 2.5 x 1.1 um discs) in the gaps of the RBC grid: half a pitch off in x and z
+            plt_t = runner.add_cell_type(host.CellType.plt(P))
+            pick = np.arange(0, len(centres), max(1, int(round(1.0 / args.plt_ratio))))
+            pc = centres[pick] + np.array([9.5, 0.0, 0.0]); pc[:, 2] += np.where(pc[:, 2] > args.nz / 2, -4.6, 4.6)
+            pa = np.tile(np.array([90.0, 0.0, 0.0]), (len(pc), 1))
+            n_plt = runner.load_cells(plt_t, pc, pa)
+            n_cells += n_plt
     runner.prepare()
     nverts_local = runner.owned_vertices()
 
@@ -162,7 +171,7 @@ def main():
         tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0]); nverts = int(tsum[1])
-        n_cells = nverts // 642
+        n_cells = nverts // 642 if args.plt_ratio == 0 else n_cells
     else:
         nverts = nverts_local
 
@@ -200,9 +209,9 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "vertex_updates_per_s": nverts * args.steps / elapsed,
             "config": {"workload": "examples/pipeflow synthetic: pipe %dx%dx%d (x periodic, analytic cylinder R=%.0f, bounce-back), "
-                                   "%d RBC (rbcHighOrderModel, 642 vertices each, target Hct %.2f), tau=%.2f, "
+                                   "%d cells (rbcHighOrderModel, 642 vertices each, target Hct %.2f; pltSimpleModel platelets per RBC: %g), tau=%.2f, "
                                    "stepParticleEvery=5, stepMaterialEvery=20%s"
-                                   % (nxg, args.ny, args.nz, R, n_cells, args.hematocrit, P.tau, (", fully periodic box without walls (cases/performance_testing)" if args.periodic_box else ", fluid only") if args.fluid_only else ""),
+                                   % (nxg, args.ny, args.nz, R, n_cells, args.hematocrit, args.plt_ratio, P.tau, (", fully periodic box without walls (cases/performance_testing)" if args.periodic_box else ", fluid only") if args.fluid_only else ""),
                        "lattice": [nxg, args.ny, args.nz], "cells": n_cells, "vertices": nverts,
                        "parallelism": "x-slabs x%d, RCCL halo exchange" % world},
             "roofline": {"bound": "hbm", "kernel": "collide_stream_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

@@ -79,6 +79,9 @@ SIGNATURES = {
     "hcp_upload": (C.c_int, [VP, C.c_int, c_double_p]),
     "hcp_download_cell_ids": (C.c_int, [VP, c_long_p]),
     "hcp_add_vertex_force": (C.c_int, [VP, c_long_p, C.c_int, c_double_p]),
+    "hcp_set_repulsion": (C.c_int, [VP, C.c_double, C.c_double, C.c_int]),
+    "hcp_repulsion": (C.c_int, [VP]),
+    "hcp_download_repulsion": (C.c_int, [VP, c_double_p]),
     "hcp_spread": (C.c_int, [VP, C.c_int]),
     "hcp_interpolate": (C.c_int, [VP]),
     "hcp_advance": (C.c_int, [VP, C.c_int]),

@@ -322,8 +322,15 @@ class HemoCell {
     hlog << "(HemoCell) (Timescale separation) Setting update separation of all particles to " << separation << " timesteps" << endl;
     cellfields->particleVelocityUpdateTimescale = separation;
   }
-  void setRepulsion(T, T) { hlog << "(HemoCell) (Repulsion) not available in the GPU back end yet" << endl; std::exit(1); }
-  void setRepulsionTimeScaleSeperation(unsigned int) {}
+  void setRepulsion(T repulsionConstant, T repulsionCutoff) {   // core/hemoCell.cpp:420-426 (cut-off in micrometres)
+    hlog << "(HemoCell) (Repulsion) Setting repulsion constant to " << repulsionConstant << ". repulsionCutoff to" << repulsionCutoff << " µm" << endl;
+    repulsionConstant_ = repulsionConstant; repulsionCutoff_ = repulsionCutoff * (1e-6 / Parameters::dx);
+    repulsionEnabled = true; repulsionPushed = false;
+  }
+  void setRepulsionTimeScaleSeperation(unsigned int separation) {   // :394-397
+    hlog << "(HemoCell) (Repulsion Timescale Seperation) Setting seperation to " << separation << " timesteps" << endl;
+    repulsionTimescale = separation; repulsionPushed = false;
+  }
   void enableBoundaryParticles(T, T, unsigned int = 1) { hlog << "(HemoCell) boundary particles are not available in the GPU back end yet" << endl; std::exit(1); }
   void setInitialMinimumDistanceFromSolid(string name, T distance) {   // core/hemoCell.cpp:410-418 (micrometres, stored as unsigned int)
     (*cellfields)[name]->minimumDistanceFromSolid = (unsigned int)distance;
@@ -336,6 +343,7 @@ class HemoCell {
   void writeOutput();
   void iterate() {
     hc_cells *c = cellfields->device();
+    if (repulsionEnabled && !repulsionPushed) { hc_check(hcp_set_repulsion(c, repulsionConstant_, repulsionCutoff_, (int)repulsionTimescale), "hcp_set_repulsion"); repulsionPushed = true; }
     long it = iter;
     hc_check(hc_iterate(lattice->device(), c, &it, 1, (int)cellfields->particleVelocityUpdateTimescale, /*force_limit=*/1, /*deletion check=*/1), "iterate");
     lattice->mark_stepped();
@@ -343,6 +351,7 @@ class HemoCell {
   }
 
   bool outputInSiUnits = true;
+  bool repulsionEnabled = false, repulsionPushed = false; T repulsionConstant_ = 0, repulsionCutoff_ = 0; unsigned int repulsionTimescale = 1;
   MultiBlockLattice3D<T, DESCRIPTOR> *lattice = nullptr;
   Config *cfg = nullptr;
   HemoCellFields *cellfields = nullptr;

@@ -22,6 +22,7 @@
 // and (with -ffp-contract=off) bit-identical to the scatter form.
 #include "common.h"
 #include "mesh.h"
+#include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -58,6 +59,10 @@ struct hc_cells {
   int *h_ntag = nullptr;         // pinned host copy of the tag counter
   int *d_ntag = nullptr;         // device counter of tagged cells
   int *d_vert_cell = nullptr;    // [cap] cell slot of every vertex
+  // vertex-vertex repulsion (core/hemoCellParticleField.cpp:677-743); arrays exist only once it is enabled
+  double *rep[3] = {nullptr, nullptr, nullptr};
+  int rep_enabled = 0, rep_timescale = 1; double rep_const = 0, rep_cutoff = 0;
+  unsigned int *d_keys[2] = {nullptr, nullptr}; int *d_vals[2] = {nullptr, nullptr}; void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0; long sort_cap = 0;
   int *d_iscratch[2] = {nullptr, nullptr};   // staged slot lists of the envelope exchange (stream ordered, no sync)
   size_t iscratch_cap[2] = {0, 0};
   long n_deleted = 0;
@@ -146,7 +151,8 @@ __device__ __forceinline__ void phi2_stencil(const LatView &v, double px, double
 // ----------------------------------------------------------------------------
 // spread
 __global__ __launch_bounds__(256) void ibm_spread_kernel(LatView v, long n, const double *px, const double *py, const double *pz,
-                                                         double *fx, double *fy, double *fz, double *F, int limit_on, double f_limit) {
+                                                         double *fx, double *fy, double *fz, const double *rx, const double *ry, const double *rz,
+                                                         double *F, int limit_on, double f_limit) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   double f0 = fx[i], f1 = fy[i], f2 = fz[i];
@@ -163,11 +169,11 @@ __global__ __launch_bounds__(256) void ibm_spread_kernel(LatView v, long n, cons
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     if (s.node[k] < 0) continue;
-    // external.data[d] += (force_repulsion[d] + force[d]) * weight  (:857-859); repulsion is 0 (disabled in scope)
     v.dirty[s.node[k] >> 4] = v.epoch;
-    unsafeAtomicAdd(&F[s.node[k]], (0.0 + f0) * s.w[k]);
-    unsafeAtomicAdd(&F[v.npad + s.node[k]], (0.0 + f1) * s.w[k]);
-    unsafeAtomicAdd(&F[2 * v.npad + s.node[k]], (0.0 + f2) * s.w[k]);
+    // external.data[d] += (force_repulsion[d] + force[d]) * weight  (:857-859)
+    unsafeAtomicAdd(&F[s.node[k]], ((rx ? rx[i] : 0.0) + f0) * s.w[k]);
+    unsafeAtomicAdd(&F[v.npad + s.node[k]], ((ry ? ry[i] : 0.0) + f1) * s.w[k]);
+    unsafeAtomicAdd(&F[2 * v.npad + s.node[k]], ((rz ? rz[i] : 0.0) + f2) * s.w[k]);
   }
 }
 
@@ -354,7 +360,8 @@ __device__ __forceinline__ bool cell_prologue(const LatView &v, int nv, long bas
 }
 
 __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv, const double *px, const double *py, const double *pz,
-                                                              double *fx, double *fy, double *fz, double *F, int limit_on, double f_limit) {
+                                                              double *fx, double *fy, double *fz, const double *rx, const double *ry, const double *rz,
+                                                              double *F, int limit_on, double f_limit) {
   __shared__ double tile[TILE_CAP];
   __shared__ unsigned char mt[TILE_CAP];
   __shared__ int s_red[6 * MAXW];
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv,
     for (int i = tid; i < nv; i += nth) {
       Stencil s;
       phi2_stencil(v, px[base + i], py[base + i], pz[base + i], s);
-      const double f0 = 0.0 + fx[base + i], f1 = 0.0 + fy[base + i], f2 = 0.0 + fz[base + i];
+      const double f0 = (rx ? rx[base + i] : 0.0) + fx[base + i], f1 = (ry ? ry[base + i] : 0.0) + fy[base + i], f2 = (rz ? rz[base + i] : 0.0) + fz[base + i];
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         if (s.node[k] < 0) continue;
@@ -389,6 +396,7 @@ __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv,
   const int sy = t.e[2], sx = t.e[1] * t.e[2];
   for (int comp = 0; comp < 3; comp++) {
     const double *fc = comp == 0 ? fx : comp == 1 ? fy : fz;
+    const double *rc = comp == 0 ? rx : comp == 1 ? ry : rz;
     double *Fc = F + (long)comp * v.npad;
     for (int i = tid; i < t.vol; i += nth) tile[i] = 0.0;
     __syncthreads();
@@ -396,7 +404,7 @@ __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv,
     for (int j = 0; j < NVPT; j++) {
       const int i = tid + j * nth;
       if (i >= nv) continue;
-      const double f = 0.0 + fc[base + i];   // force_repulsion (0: disabled in scope) + force, :857-859
+      const double f = (rc ? rc[base + i] : 0.0) + fc[base + i];   // force_repulsion + force, :857-859
 #pragma unroll
       for (int k = 0; k < 8; k++)
         if (vs[j].adm & (1u << k)) atomicAdd(&tile[vs[j].base + (k >> 2) * sx + ((k >> 1) & 1) * sy + (k & 1)], f * vs[j].w[k]);
@@ -790,7 +798,7 @@ __global__ __launch_bounds__(256) void cell_extent_kernel(int nv, const double *
   if (tid == 0) { out[3 * blockIdx.x] = lo[0]; out[3 * blockIdx.x + 1] = hi[0]; out[3 * blockIdx.x + 2] = (double)own[0]; }
 }
 
-struct VertArrays { double *p[3], *v[3], *f[3]; };
+struct VertArrays { double *p[3], *v[3], *f[3], *r[3]; };   // r: repulsion force arrays or null
 
 // record layout per vertex: pos[3] vel[3] force[3] (the fields of serializeValues_t that change, core/hemoCellParticle.h:45-63)
 __global__ __launch_bounds__(256) void pack_cells_kernel(int nv, const int *slots, VertArrays a, double *buf, double x_shift) {
@@ -820,6 +828,7 @@ __global__ __launch_bounds__(256) void unpack_cells_kernel(int nv, const int *sl
       a.p[0][dst + i] = r[0]; a.p[1][dst + i] = r[1]; a.p[2][dst + i] = r[2];
       a.v[0][dst + i] = r[3]; a.v[1][dst + i] = r[4]; a.v[2][dst + i] = r[5];
       a.f[0][dst + i] = r[6]; a.f[1][dst + i] = r[7]; a.f[2][dst + i] = r[8];
+      if (fresh && a.r[0]) { a.r[0][dst + i] = 0.0; a.r[1][dst + i] = 0.0; a.r[2][dst + i] = 0.0; }   // until the next evaluation
     }
   }
 }
@@ -827,7 +836,10 @@ __global__ __launch_bounds__(256) void unpack_cells_kernel(int nv, const int *sl
 __global__ __launch_bounds__(256) void move_cells_kernel(int nv, const int *src_slots, const int *dst_slots, VertArrays a) {
   const long src = (long)src_slots[blockIdx.x] * nv, dst = (long)dst_slots[blockIdx.x] * nv;
   for (int i = threadIdx.x; i < nv; i += 256)
-    for (int d = 0; d < 3; d++) { a.p[d][dst + i] = a.p[d][src + i]; a.v[d][dst + i] = a.v[d][src + i]; a.f[d][dst + i] = a.f[d][src + i]; }
+    for (int d = 0; d < 3; d++) {
+      a.p[d][dst + i] = a.p[d][src + i]; a.v[d][dst + i] = a.v[d][src + i]; a.f[d][dst + i] = a.f[d][src + i];
+      if (a.r[d]) a.r[d][dst + i] = a.r[d][src + i];
+    }
 }
 
 __global__ __launch_bounds__(256) void owned_count_kernel(long n, const double *px, int x0, int nx, unsigned long long *count) {
@@ -836,6 +848,68 @@ __global__ __launch_bounds__(256) void owned_count_kernel(long n, const double *
   if (i < n) { const long gx = nearest_node(px[i]) - x0; mine = (gx >= 0 && gx < nx) ? 1 : 0; }
   const unsigned long long b = __ballot(mine);
   if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (unsigned long long)__popcll(b));
+}
+
+// ---------------------------------------------------------------------------- vertex-vertex repulsion
+// applyRepulsionForce (core/hemoCellParticleField.cpp:677-743): vertices are binned by their nearest lattice
+// node (update_pg, :137-168); two vertices of DIFFERENT cells in the same or in adjacent bins that are closer
+// than r_cutoff repel each other with r_const * (r_cutoff / d) along their separation.  The reference visits a
+// same-bin pair twice (its inner loop runs over ordered pairs there), so those pairs count double.  Gather form:
+// every vertex sums over the 27 bins around its own; the bins come from a radix sort of (bin, vertex).
+__global__ void rep_keys_kernel(LatView v, long n, long first, long packed0, const double *px, const double *py, const double *pz, unsigned int *keys, int *vals) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  long lx = nearest_node(px[i]) - v.x0, ly = nearest_node(py[i]), lz = nearest_node(pz[i]);
+  bool ok = true;
+  if (v.wrap_x) lx = pmod(lx, v.nx); else ok = ok && (lx >= -HALO && lx < v.nx + HALO);
+  if (ly < 0 || ly >= v.ny) { if (v.per_y) ly = pmod(ly, v.ny); else ok = false; }
+  if (lz < 0 || lz >= v.nz) { if (v.per_z) lz = pmod(lz, v.nz); else ok = false; }
+  keys[packed0 + i] = ok ? (unsigned int)((lx + HALO) * (long)v.plane + ly * v.nz + lz) : 0xffffffffu;
+  vals[packed0 + i] = (int)(first + i);
+}
+
+__device__ __forceinline__ long lower_bound_u32(const unsigned int *a, long n, unsigned int key) {
+  long lo = 0, hi = n;
+  while (lo < hi) { const long mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void rep_force_kernel(LatView v, long cap, long nsorted, const unsigned int *keys, const int *vals, const int *vert_cell,
+                                                        const double *px, const double *py, const double *pz, double *rx, double *ry, double *rz,
+                                                        double r_const, double r_cutoff) {
+  const long s = (long)blockIdx.x * 256 + threadIdx.x;   // position in the sorted order
+  if (s >= nsorted) return;
+  const unsigned int key = keys[s];
+  const int i = vals[s];
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  if (key != 0xffffffffu) {
+    const int lz = key % v.nz, ly = (key / v.nz) % v.ny, lxp = key / v.plane;   // lxp = padded x
+    const double x = px[i], y = py[i], z = pz[i];
+    const int ci = vert_cell[i];
+    for (int dx = -1; dx <= 1; dx++)
+      for (int dy = -1; dy <= 1; dy++)
+        for (int dz = -1; dz <= 1; dz++) {
+          long bx = lxp + dx, by = ly + dy, bz = lz + dz;
+          double sx = 0.0, sy = 0.0, sz = 0.0;   // minimum-image shift applied to the neighbour's position
+          if (v.wrap_x) { if (bx < HALO) { bx += v.nx; sx = -(double)v.nx; } else if (bx >= v.nx + HALO) { bx -= v.nx; sx = (double)v.nx; } }
+          else if (bx < 0 || bx >= v.nx + 2 * HALO) continue;
+          if (by < 0) { if (!v.per_y) continue; by += v.ny; sy = -(double)v.ny; } else if (by >= v.ny) { if (!v.per_y) continue; by -= v.ny; sy = (double)v.ny; }
+          if (bz < 0) { if (!v.per_z) continue; bz += v.nz; sz = -(double)v.nz; } else if (bz >= v.nz) { if (!v.per_z) continue; bz -= v.nz; sz = (double)v.nz; }
+          const unsigned int nkey = (unsigned int)(bx * (long)v.plane + by * v.nz + bz);
+          const double fac = (dx == 0 && dy == 0 && dz == 0) ? 2.0 : 1.0;
+          for (long q = lower_bound_u32(keys, nsorted, nkey); q < nsorted && keys[q] == nkey; q++) {
+            const int j = vals[q];
+            if (j == i || vert_cell[j] == ci) continue;
+            const double d0 = x - (px[j] + sx), d1 = y - (py[j] + sy), d2 = z - (pz[j] + sz);
+            const double dist = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+            if (dist < r_cutoff) {
+              const double m = fac * (r_const * (1 / (dist / r_cutoff)));
+              a0 += m * (d0 / dist); a1 += m * (d1 / dist); a2 += m * (d2 / dist);
+            }
+          }
+        }
+  }
+  rx[i] = a0; ry[i] = a1; rz[i] = a2;
 }
 
 __global__ void fill_vert_cell_kernel(long n, int nv, int cell0, long first, int *vert_cell) {
@@ -877,6 +951,10 @@ static int free_device_arrays(hc_cells *C) {
   for (int t = 0; t < 8; t++) C->capc[t] = 0;
   if (C->d_vert_cell) hipFree(C->d_vert_cell);
   C->d_vert_cell = nullptr;
+  for (int d = 0; d < 3; d++) { if (C->rep[d]) hipFree(C->rep[d]); C->rep[d] = nullptr; }
+  for (int k = 0; k < 2; k++) { if (C->d_keys[k]) hipFree(C->d_keys[k]); if (C->d_vals[k]) hipFree(C->d_vals[k]); C->d_keys[k] = nullptr; C->d_vals[k] = nullptr; }
+  if (C->d_sort_tmp) hipFree(C->d_sort_tmp);
+  C->d_sort_tmp = nullptr; C->sort_tmp_bytes = 0; C->sort_cap = 0;
   return HC_OK;
 }
 
@@ -905,6 +983,7 @@ static int sync_to_device(hc_cells *C) {
       HC_HIP(hipMalloc((void **)&C->frc[d], C->cap * sizeof(double)));
     }
     HC_HIP(hipMalloc((void **)&C->d_vert_cell, C->cap * sizeof(int)));
+    if (C->rep_enabled) for (int d = 0; d < 3; d++) { HC_HIP(hipMalloc((void **)&C->rep[d], C->cap * sizeof(double))); HC_HIP(hipMemset(C->rep[d], 0, C->cap * sizeof(double))); }
     C->tag_cap = capcells + 1;
     HC_HIP(hipMalloc((void **)&C->d_tag, C->tag_cap * sizeof(int)));
     for (int t = 0; t < C->ntypes; t++) {
@@ -1249,14 +1328,15 @@ int hcp_spread(hc_cells *C, int force_limit) {
     const long n = C->ncells[t] * C->types[t]->host.nv, f = C->first[t];
     if (n == 0) continue;
     const int nv = C->types[t]->host.nv;
+    const double *rp[3] = {C->rep_enabled ? C->rep[0] + f : nullptr, C->rep_enabled ? C->rep[1] + f : nullptr, C->rep_enabled ? C->rep[2] + f : nullptr};
     if (g_ibm_per_vertex)
       hipLaunchKernelGGL(ibm_spread_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), v, n,
                          (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
-                         C->frc[0] + f, C->frc[1] + f, C->frc[2] + f, C->L->force[C->L->fcur], force_limit, C->P.f_limit);
+                         C->frc[0] + f, C->frc[1] + f, C->frc[2] + f, rp[0], rp[1], rp[2], C->L->force[C->L->fcur], force_limit, C->P.f_limit);
     else
       hipLaunchKernelGGL(ibm_spread_cell_kernel, dim3((unsigned)C->ncells[t]), dim3(nv > 128 ? 256 : 128), 0, hc::stream(), v, nv,
                          (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
-                         C->frc[0] + f, C->frc[1] + f, C->frc[2] + f, C->L->force[C->L->fcur], force_limit, C->P.f_limit);
+                         C->frc[0] + f, C->frc[1] + f, C->frc[2] + f, rp[0], rp[1], rp[2], C->L->force[C->L->fcur], force_limit, C->P.f_limit);
     HC_HIP(hipGetLastError());
   }
   return HC_OK;
@@ -1393,7 +1473,8 @@ int hc_iterate(hc_lattice *L, hc_cells *C, long *iter, int n, int particle_times
   int rc;
   for (int s = 0; s < n; s++) {
     const long it = *iter;
-    if ((rc = hcp_spread(C, force_limit)) != HC_OK) return rc;                  // core/hemoCell.cpp:313
+    if (C->rep_enabled && it % C->rep_timescale == 0) { if ((rc = hcp_repulsion(C)) != HC_OK) return rc; }   // core/hemoCell.cpp:307-309
+    if ((rc = hcp_spread(C, force_limit)) != HC_OK) return rc;                  // :313
     if ((rc = hcl_collide_stream_part(L, 0)) != HC_OK) return rc;               // :317
     hcl_step_end(L);
     if (it % particle_timescale == 0) { if ((rc = hcp_interpolate(C)) != HC_OK) return rc; }   // :327-332
@@ -1409,7 +1490,10 @@ int hc_iterate(hc_lattice *L, hc_cells *C, long *iter, int n, int particle_times
 // ---------------------------------------------------------------------------- multi-slab cell exchange (host side)
 static VertArrays vert_arrays(hc_cells *C, int t) {
   VertArrays a;
-  for (int d = 0; d < 3; d++) { a.p[d] = C->pos[d] + C->first[t]; a.v[d] = C->vel[d] + C->first[t]; a.f[d] = C->frc[d] + C->first[t]; }
+  for (int d = 0; d < 3; d++) {
+    a.p[d] = C->pos[d] + C->first[t]; a.v[d] = C->vel[d] + C->first[t]; a.f[d] = C->frc[d] + C->first[t];
+    a.r[d] = C->rep[d] ? C->rep[d] + C->first[t] : nullptr;
+  }
   return a;
 }
 // stage a small host int array on the device in a persistent scratch slot; the copy and every later use are
@@ -1542,6 +1626,79 @@ int hcp_owned_vertices(hc_cells *C, long *n_owned) {
   hipFree(d);
   if (e != hipSuccess) return hc::hip_fail(e, "hcp_owned_vertices", __FILE__, __LINE__);
   *n_owned = (long)h;
+  return HC_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+// hemocell.setRepulsion(k, cutoff_um) + setRepulsionTimeScaleSeperation (core/hemoCell.cpp:394-397,420-426)
+int hcp_set_repulsion(hc_cells *C, double r_const, double r_cutoff_lu, int timescale) {
+  HC_REQUIRE(C && r_cutoff_lu > 0 && timescale >= 1, "hcp_set_repulsion: bad arguments");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  C->rep_const = r_const; C->rep_cutoff = r_cutoff_lu; C->rep_timescale = timescale;
+  if (!C->rep_enabled) {
+    C->rep_enabled = 1;
+    if (C->cap > 0) for (int d = 0; d < 3; d++) { HC_HIP(hipMalloc((void **)&C->rep[d], C->cap * sizeof(double))); HC_HIP(hipMemset(C->rep[d], 0, C->cap * sizeof(double))); }
+  }
+  return HC_OK;
+}
+
+// cellfields->applyRepulsionForce() (core/hemoCell.cpp:307-309 -> core/hemoCellParticleField.cpp:696-743)
+int hcp_repulsion(hc_cells *C) {
+  HC_REQUIRE(C, "hcp_repulsion: null pointer");
+  HC_REQUIRE(C->rep_enabled, "hcp_repulsion: call hcp_set_repulsion first");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  if (C->nverts == 0) return HC_OK;
+  if (!C->rep[0]) for (int d = 0; d < 3; d++) { HC_HIP(hipMalloc((void **)&C->rep[d], C->cap * sizeof(double))); HC_HIP(hipMemset(C->rep[d], 0, C->cap * sizeof(double))); }
+  const long n = C->nverts;
+  if (n > C->sort_cap) {
+    HC_HIP(hipStreamSynchronize(hc::stream()));
+    for (int k = 0; k < 2; k++) { if (C->d_keys[k]) HC_HIP(hipFree(C->d_keys[k])); if (C->d_vals[k]) HC_HIP(hipFree(C->d_vals[k])); }
+    if (C->d_sort_tmp) HC_HIP(hipFree(C->d_sort_tmp));
+    C->sort_cap = n + n / 4 + 1024;
+    for (int k = 0; k < 2; k++) { HC_HIP(hipMalloc((void **)&C->d_keys[k], C->sort_cap * sizeof(unsigned int))); HC_HIP(hipMalloc((void **)&C->d_vals[k], C->sort_cap * sizeof(int))); }
+    C->sort_tmp_bytes = 0; C->d_sort_tmp = nullptr;
+    HC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, C->sort_tmp_bytes, C->d_keys[0], C->d_keys[1], C->d_vals[0], C->d_vals[1], (int)C->sort_cap, 0, 32, hc::stream()));
+    HC_HIP(hipMalloc(&C->d_sort_tmp, C->sort_tmp_bytes));
+  }
+  const LatView v = make_view(C->L);
+  long packed0 = 0;
+  for (int t = 0; t < C->ntypes; t++) {
+    const long nt = C->ncells[t] * C->types[t]->host.nv, f = C->first[t];
+    if (nt == 0) continue;
+    hipLaunchKernelGGL(rep_keys_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, hc::stream(), v, nt, f, packed0,
+                       (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f), C->d_keys[0], C->d_vals[0]);
+    HC_HIP(hipGetLastError());
+    packed0 += nt;
+  }
+  size_t tmp = C->sort_tmp_bytes;
+  HC_HIP(hipcub::DeviceRadixSort::SortPairs(C->d_sort_tmp, tmp, C->d_keys[0], C->d_keys[1], C->d_vals[0], C->d_vals[1], (int)n, 0, 32, hc::stream()));
+  hipLaunchKernelGGL(rep_force_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), v, C->cap, n, (const unsigned int *)C->d_keys[1],
+                     (const int *)C->d_vals[1], (const int *)C->d_vert_cell, (const double *)C->pos[0], (const double *)C->pos[1], (const double *)C->pos[2],
+                     C->rep[0], C->rep[1], C->rep[2], C->rep_const, C->rep_cutoff);
+  HC_HIP(hipGetLastError());
+  return HC_OK;
+}
+
+// force_repulsion of every vertex, [n][3] in download order
+int hcp_download_repulsion(hc_cells *C, double *out) {
+  HC_REQUIRE(C && out, "hcp_download_repulsion: null pointer");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  HC_HIP(hipStreamSynchronize(hc::stream()));
+  std::vector<double> tmp;
+  size_t o = 0;
+  for (int t = 0; t < C->ntypes; t++) {
+    const long n = C->ncells[t] * C->types[t]->host.nv;
+    tmp.resize((size_t)n);
+    for (int d = 0; d < 3; d++) {
+      if (n && C->rep[d]) HC_HIP(hipMemcpy(tmp.data(), C->rep[d] + C->first[t], (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+      else std::fill(tmp.begin(), tmp.end(), 0.0);
+      for (long i = 0; i < n; i++) out[o + 3 * (size_t)i + d] = tmp[(size_t)i];
+    }
+    o += 3 * (size_t)n;
+  }
   return HC_OK;
 }
 

@@ -267,6 +267,19 @@ class Cells:
         ff = np.ascontiguousarray(f, dtype=np.float64).reshape(len(idx), 3)
         check(self.lib.hcp_add_vertex_force(self.ptr, lptr(idx), len(idx), dptr(ff)))
 
+    def setRepulsion(self, r_const, r_cutoff_um, timescale=1):
+        """hemocell.setRepulsion(k, cutoff [um]) + setRepulsionTimeScaleSeperation(timescale)"""
+        check(self.lib.hcp_set_repulsion(self.ptr, float(r_const), float(r_cutoff_um) * (1e-6 / self.P.dx), int(timescale)))
+
+    def applyRepulsionForce(self):
+        check(self.lib.hcp_repulsion(self.ptr))
+
+    @property
+    def repulsion_forces(self):
+        out = np.empty((self.counts()[0], 3), dtype=np.float64)
+        check(self.lib.hcp_download_repulsion(self.ptr, dptr(out)))
+        return out
+
     def spreadParticleForce(self, force_limit=True):
         check(self.lib.hcp_spread(self.ptr, int(force_limit)))
 

@@ -154,6 +154,13 @@ int hcp_upload(hc_cells *C, int what, const double *in);
 int hcp_download_cell_ids(hc_cells *C, long *ids);
 /* HemoCellStretch::ForceForcedLsps (helper/hemoCellStretch.cpp:63-78): sv.force += f on listed vertices */
 int hcp_add_vertex_force(hc_cells *C, const long *vertex_index, int n, const double *f /*[n][3]*/);
+/* hemocell.setRepulsion(k, cutoff) + setRepulsionTimeScaleSeperation (core/hemoCell.cpp:394-397,420-426); the
+ * cutoff is given in lattice units (the facade converts from micrometres).  hc_iterate then evaluates
+ * cellfields->applyRepulsionForce() (core/hemoCell.cpp:307-309 -> core/hemoCellParticleField.cpp:677-743) every
+ * `timescale` iterations; spread adds force_repulsion + force as the reference does. */
+int hcp_set_repulsion(hc_cells *C, double r_const, double r_cutoff_lu, int timescale);
+int hcp_repulsion(hc_cells *C);
+int hcp_download_repulsion(hc_cells *C, double *out /*[n][3]*/);
 /* cellfields->spreadParticleForce() (core/hemoCell.cpp:313 -> core/hemoCellParticleField.cpp:841-863) */
 int hcp_spread(hc_cells *C, int force_limit);
 /* cellfields->interpolateFluidVelocity() (core/hemoCell.cpp:329 -> core/hemoCellParticleField.cpp:819-839) */

@@ -781,6 +781,7 @@ orc_sim *orc_sim_create(orc_lattice *L, const orc_params *P) {
   S->L = L; S->P = *P;
   S->particle_velocity_timescale = 1;
   S->force_limit_enabled = 1;
+  S->rep_enabled = 0; S->rep_timescale = 1;
   return S;
 }
 void orc_sim_destroy(orc_sim *S) {
@@ -978,9 +979,69 @@ void orc_sim_add_vertex_force(orc_sim *S, long particle, const double f[3]) {
   for (int d = 0; d < 3; d++) S->particles[particle].force[d] += f[d];
 }
 
+/* HemoCellParticleField::applyRepulsionForce, core/hemoCellParticleField.cpp:677-743, with the particle grid of
+ * update_pg (:137-168): particles binned by nearest node; for every bin the reference visits the bin itself
+ * (ordered pairs, so every same-bin pair is applied twice) and 13 of its 26 neighbours (each adjacent pair of bins
+ * once).  One global block: bins wrap in periodic directions and the neighbour's position is shifted by the
+ * domain length (what the reference's periodic envelope copies carry). */
+void orc_sim_repulsion(orc_sim *S, double r_const, double r_cutoff) {
+  const orc_lattice *L = S->L;
+  const int dims[3] = {L->nx, L->ny, L->nz};
+  const long nb = (long)L->nx * L->ny * L->nz;
+  long *head = (long *)malloc(sizeof(long) * (size_t)nb), *tail = (long *)malloc(sizeof(long) * (size_t)nb), *next = (long *)malloc(sizeof(long) * (size_t)(S->np > 0 ? S->np : 1));
+  for (long b = 0; b < nb; b++) head[b] = tail[b] = -1;
+  for (long p = 0; p < S->np; p++) {
+    orc_particle *pt = S->particles + p;
+    pt->force_repulsion[0] = pt->force_repulsion[1] = pt->force_repulsion[2] = 0.;
+    long c[3]; int ok = 1;
+    for (int d = 0; d < 3; d++) {
+      c[d] = (long)floor(pt->position[d] + 0.5);
+      if (c[d] < 0 || c[d] >= dims[d]) { if (L->periodic[d]) c[d] = ((c[d] % dims[d]) + dims[d]) % dims[d]; else ok = 0; }
+    }
+    next[p] = -1;
+    if (!ok) continue;
+    const long b = c[2] + (long)L->nz * (c[1] + (long)L->ny * c[0]);
+    if (head[b] < 0) head[b] = p; else next[tail[b]] = p;   /* insertion order = particle order, as particle_grid[index][k] */
+    tail[b] = p;
+  }
+  static const int half[14][3] = {{0, 0, 0}, {0, 0, 1}, {0, 1, 0}, {0, 1, 1}, {1, -1, -1}, {1, -1, 0}, {1, -1, 1}, {1, 0, -1}, {1, 0, 0},
+                                  {1, 0, 1}, {1, 1, -1}, {1, 1, 0}, {1, 1, 1}, {0, 1, -1}};
+  for (int x = 0; x < L->nx; x++) for (int y = 0; y < L->ny; y++) for (int z = 0; z < L->nz; z++) {
+    const long lb = z + (long)L->nz * (y + (long)L->ny * x);
+    if (head[lb] < 0) continue;
+    for (int h = 0; h < 14; h++) {
+      long n[3] = {x + half[h][0], y + half[h][1], z + half[h][2]}; double shift[3] = {0, 0, 0}; int ok = 1;
+      for (int d = 0; d < 3; d++) {
+        if (n[d] < 0) { if (L->periodic[d]) { n[d] += dims[d]; shift[d] = -(double)dims[d]; } else ok = 0; }
+        else if (n[d] >= dims[d]) { if (L->periodic[d]) { n[d] -= dims[d]; shift[d] = (double)dims[d]; } else ok = 0; }
+      }
+      if (!ok) continue;
+      const long nbn = n[2] + (long)L->nz * (n[1] + (long)L->ny * n[0]);
+      for (long i = head[lb]; i >= 0; i = next[i])
+        for (long j = head[nbn]; j >= 0; j = next[j]) {
+          orc_particle *lp = S->particles + i, *np_ = S->particles + j;
+          if (np_ == lp) continue;
+          if (lp->cellId == np_->cellId && lp->celltype == np_->celltype) continue;
+          double dv[3];
+          for (int d = 0; d < 3; d++) dv[d] = lp->position[d] - (np_->position[d] + shift[d]);
+          const double distance = sqrt(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+          if (distance < r_cutoff) {
+            for (int d = 0; d < 3; d++) {
+              const double rfm = r_const * (1 / (distance / r_cutoff)) * (dv[d] / distance);
+              lp->force_repulsion[d] = lp->force_repulsion[d] + rfm;
+              np_->force_repulsion[d] = np_->force_repulsion[d] - rfm;
+            }
+          }
+        }
+    }
+  }
+  free(head); free(tail); free(next);
+}
+
 /* HemoCell::iterate, core/hemoCell.cpp:299-376, followed by the driver's
  * setExternalVector(body force) (examples/pipeflow/pipeflow.cpp:144-146) */
 void orc_sim_iterate(orc_sim *S) {
+  if (S->rep_enabled && S->iter % S->rep_timescale == 0) orc_sim_repulsion(S, S->rep_const, S->rep_cutoff);   /* :307-309 */
   orc_sim_spread(S);                                            /* :313 */
   orc_collide_stream(S->L);                                     /* :317 */
   if (S->iter % S->particle_velocity_timescale == 0) orc_sim_interpolate(S); /* :327-332 */

@@ -469,3 +469,36 @@ def test_long_run_stays_bounded(gpu):
     assert np.isfinite(ux).all() and 0 < ux.mean() and ux.max() < 1.2 * u_max
     assert (info["position"][:, 0] > c[:, 0] + 1.0).mean() > 0.8      # the cells were carried downstream
     L.destroy()
+
+
+def test_repulsion_vs_oracle(orc, gpu):
+    """applyRepulsionForce (core/hemoCellParticleField.cpp:677-743): two RBCs and a platelet brought within the
+    cut-off of each other, one pair across the periodic seam.  force_repulsion per vertex vs the oracle, then 30
+    coupled iterations with repulsion every 2nd iteration (spread adds force_repulsion + force)."""
+    nx, ny, nz = 48, 34, 34
+    mask, R = gpu.pipe_mask(nx, ny, nz)
+    Po, Lo, Lg, So, hg = _sim_pair(orc, gpu, nx, ny, nz, (1, 0, 0), mask, plt=True)
+    assert _add_both(orc, So, hg, 0, (14.0, 16.5, 15.2), (90, 0, 0))
+    assert _add_both(orc, So, hg, 0, (15.0, 16.5, 18.4), (90, 0, 0))      # 3.2 lu above the first: membranes ~0.7 lu apart
+    assert _add_both(orc, So, hg, 0, (45.5, 16.5, 13.0), (90, 0, 0))      # reaches through the periodic seam ...
+    assert _add_both(orc, So, hg, 0, (46.5, 16.5, 16.2), (90, 0, 0))      # ... and so does its close neighbour
+    assert _add_both(orc, So, hg, 1, (21.5, 16.5, 14.0), (0, 0, 0))       # platelet next to the first RBC's rim
+    k_rep, cutoff_um = 2e-6, 0.7                                          # cut-off 0.7 um = 1.4 lu (examples/pipeflow/config.xml:36-37)
+    cutoff = cutoff_um * (1e-6 / Po.dx)
+    hg.cellfields.setRepulsion(k_rep, cutoff_um, 2)
+    So.contents.rep_enabled = 1; So.contents.rep_timescale = 2; So.contents.rep_const = k_rep; So.contents.rep_cutoff = cutoff
+    orc.orc_sim_repulsion(So, k_rep, cutoff); hg.cellfields.applyRepulsionForce()
+    r_o = np.zeros((So.contents.np, 3)); orc.orc_sim_get(So, 3, O.dptr(r_o))
+    r_g = hg.cellfields.repulsion_forces
+    assert np.count_nonzero(np.abs(r_o).sum(1)) > 20                      # the case does exercise the law
+    assert np.abs(r_g - r_o).max() <= 1e-12 * np.abs(r_o).max(), np.abs(r_g - r_o).max()
+    assert np.abs(r_o.sum(0)).max() <= 1e-12 * np.abs(r_o).sum()          # action = reaction
+    orc.orc_sim_mechanics(So, 1); hg.cellfields.applyConstitutiveModel(0, True)
+    for _ in range(30):
+        orc.orc_sim_iterate(So)
+    hg.iterate(30)
+    p_o, v_o, f_o = _oracle_state(orc, So)
+    assert np.abs(hg.cellfields.positions - p_o).max() <= 1e-9
+    orc.orc_sim_get(So, 3, O.dptr(r_o))
+    assert np.abs(hg.cellfields.repulsion_forces - r_o).max() <= 1e-9 * max(np.abs(r_o).max(), 1e-30)
+    Lo.destroy(); Lg.destroy()

@@ -243,10 +243,21 @@ __global__ __launch_bounds__(256) void ibm_interpolate_kernel(LatView v, PopView
 // global atomics than one per (vertex, node, component).  Interpolate: the nodes the cell touches are
 // compacted, the node velocity (19-population gather + moments) is evaluated once per node into LDS, and
 // every vertex then blends its 8 values from LDS.
-constexpr int TILE_CAP = 6144;       // nodes per tile (18 x 18 x 18 = 5832 fits)
-constexpr int NODE_CAP = 2048;       // distinct nodes of one cell for the interpolation
+constexpr int TILE_CAP = 5832;       // nodes per tile: 18 x 18 x 18, any orientation of a 642-vertex RBC; three workgroups per CU fit the 160 KB LDS
+constexpr int NODE_CAP = 1536;       // distinct nodes of one cell for the interpolation (an RBC touches ~1300)
 
-struct Tile { int o[3]; int e[3]; int vol; };
+// bounding box of a cell's stencil nodes: origin o (global), extent e, origin ow in local wrapped coordinates,
+// reciprocals for the index decode
+struct Tile { int o[3]; int e[3]; int vol; int ow[3]; float r1, r2; };
+
+// tile index -> (tx, ty, tz) without integer division.  Exact for i < 2^16: (i + 0.5) / e is at least 0.5 / e
+// away from an integer while the float error stays below 1e-3 / e.
+__device__ __forceinline__ void tile_decode(const Tile &t, int i, int &tx, int &ty, int &tz) {
+  const int q = (int)(((float)i + 0.5f) * t.r2);
+  tz = i - q * t.e[2];
+  tx = (int)(((float)q + 0.5f) * t.r1);
+  ty = q - tx * t.e[1];
+}
 
 __device__ __forceinline__ int stencil_base(const LatView &v, double px, double py, double pz, int b[3]) {
   const double p[3] = {px, py, pz};
@@ -257,13 +268,13 @@ __device__ __forceinline__ int stencil_base(const LatView &v, double px, double 
 
 // global lattice element of tile entry i (only meaningful for entries that were admitted by a stencil)
 __device__ __forceinline__ long tile_node(const LatView &v, const Tile &t, int i, int &lx, int &ly, int &lz) {
-  const int tz = i % t.e[2], ty = (i / t.e[2]) % t.e[1], tx = i / (t.e[2] * t.e[1]);
-  long gx = (long)t.o[0] + tx - v.x0, gy = (long)t.o[1] + ty, gz = (long)t.o[2] + tz;
-  if (v.wrap_x) gx = pmod(gx, v.nx);
-  if (v.per_y) gy = pmod(gy, v.ny);
-  if (v.per_z) gz = pmod(gz, v.nz);
-  lx = (int)gx; ly = (int)gy; lz = (int)gz;
-  return (gx + HALO) * (long)v.plane + gy * v.nz + gz;
+  int tx, ty, tz;
+  tile_decode(t, i, tx, ty, tz);
+  lx = t.ow[0] + tx; ly = t.ow[1] + ty; lz = t.ow[2] + tz;
+  if (v.wrap_x && lx >= v.nx) lx -= v.nx;     // the tile is no wider than the domain (cell_prologue), one wrap suffices
+  if (v.per_y && ly >= v.ny) ly -= v.ny;
+  if (v.per_z && lz >= v.nz) lz -= v.nz;
+  return (long)(lx + HALO) * v.plane + ly * v.nz + lz;
 }
 
 // compact per-vertex stencil kept in registers across the passes of the cell kernels
@@ -295,16 +306,28 @@ __device__ __forceinline__ void block_bbox(int lo[3], int hi[3], int *s_red, Til
   t.vol = vol > 0x7fffffff ? 0x7fffffff : (int)vol;
 }
 
+// local (wrapped) origin and decode reciprocals; false when the tile cannot be used
+__device__ __forceinline__ bool tile_finish(const LatView &v, Tile &t) {
+  if (t.vol > TILE_CAP) return false;
+  if ((v.wrap_x && t.e[0] > v.nx) || (v.per_y && t.e[1] > v.ny) || (v.per_z && t.e[2] > v.nz)) return false;
+  t.ow[0] = v.wrap_x ? (int)pmod((long)t.o[0] - v.x0, v.nx) : t.o[0] - v.x0;
+  t.ow[1] = v.per_y ? (int)pmod(t.o[1], v.ny) : t.o[1];
+  t.ow[2] = v.per_z ? (int)pmod(t.o[2], v.nz) : t.o[2];
+  t.r1 = 1.0f / (float)t.e[1]; t.r2 = 1.0f / (float)t.e[2];
+  return true;
+}
+
 // mask class of tile entry i: 0 fluid, 1/2 boundary, 3 not addressable (outside the domain / halo range)
 __device__ __forceinline__ unsigned char tile_mask(const LatView &v, const Tile &t, int i) {
-  const int tz = i % t.e[2], ty = (i / t.e[2]) % t.e[1], tx = i / (t.e[2] * t.e[1]);
-  long lx = (long)t.o[0] + tx - v.x0, gy = (long)t.o[1] + ty, gz = (long)t.o[2] + tz;
-  if (v.wrap_x) lx = pmod(lx, v.nx);
+  int tx, ty, tz;
+  tile_decode(t, i, tx, ty, tz);
+  int lx = t.ow[0] + tx, ly = t.ow[1] + ty, lz = t.ow[2] + tz;
+  if (v.wrap_x) { if (lx >= v.nx) lx -= v.nx; }
   else if (v.halo_x) { if (lx < -HALO || lx >= v.nx + HALO) return 3; }
   else if (lx < 0 || lx >= v.nx) return 3;
-  if (gy < 0 || gy >= v.ny) { if (v.per_y) gy = pmod(gy, v.ny); else return 3; }
-  if (gz < 0 || gz >= v.nz) { if (v.per_z) gz = pmod(gz, v.nz); else return 3; }
-  return v.mask[(lx + HALO) * (long)v.plane + gy * v.nz + gz];
+  if (v.per_y) { if (ly >= v.ny) ly -= v.ny; } else if (ly < 0 || ly >= v.ny) return 3;
+  if (v.per_z) { if (lz >= v.nz) lz -= v.nz; } else if (lz < 0 || lz >= v.nz) return 3;
+  return v.mask[(long)(lx + HALO) * v.plane + ly * v.nz + lz];
 }
 
 // interpolationCoefficientsPhi2 against the LDS copy of the mask; same arithmetic and visiting order as phi2_stencil
@@ -348,7 +371,8 @@ __device__ __forceinline__ bool cell_prologue(const LatView &v, int nv, long bas
     }
   }
   block_bbox(lo, hi, s_red, t);
-  if (t.vol > TILE_CAP || nv > NVPT * nth) return false;
+  if (!tile_finish(v, t) || nv > NVPT * nth) return false;
+#pragma unroll 4
   for (int i = tid; i < t.vol; i += nth) mt[i] = tile_mask(v, t, i);
   __syncthreads();
 #pragma unroll
@@ -420,9 +444,12 @@ __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv,
 
 __global__ __launch_bounds__(256) void ibm_interpolate_cell_kernel(LatView v, PopView pv, int nv, const double *px, const double *py,
                                                                    const double *pz, double *vx, double *vy, double *vz) {
-  __shared__ int slot[TILE_CAP];
-  __shared__ unsigned char mt[TILE_CAP];
-  __shared__ int list[NODE_CAP];
+  // 54 KB in all, so that three workgroups share a CU: 16-bit slots, and the node list reuses the mask tile
+  // (the mask is only read while the stencils are formed)
+  constexpr unsigned short FREE = 0xFFFF, MARK = 0xFFFE;
+  __shared__ unsigned short slot[TILE_CAP];
+  __shared__ __attribute__((aligned(16))) unsigned char raw[TILE_CAP > 2 * NODE_CAP ? TILE_CAP : 2 * NODE_CAP];
+  unsigned char *mt = raw; unsigned short *list = reinterpret_cast<unsigned short *>(raw);
   __shared__ double ux[NODE_CAP], uy[NODE_CAP], uz[NODE_CAP];
   __shared__ int s_red[6 * MAXW], s_count;
   const int tid = threadIdx.x, nth = blockDim.x;
@@ -431,16 +458,16 @@ __global__ __launch_bounds__(256) void ibm_interpolate_cell_kernel(LatView v, Po
   bool tiled = cell_prologue(v, nv, base, px, py, pz, s_red, mt, t, vs);
   const int sy = t.e[2], sx = t.e[1] * t.e[2];
   if (tiled) {
-    for (int i = tid; i < t.vol; i += nth) slot[i] = -1;
+    for (int i = tid; i < t.vol; i += nth) slot[i] = FREE;
     if (tid == 0) s_count = 0;
-    __syncthreads();
+    __syncthreads();   // also: every thread is done reading mt, list may overwrite it
 #pragma unroll
     for (int j = 0; j < NVPT; j++)   // mark the admitted nodes
 #pragma unroll
-      for (int k = 0; k < 8; k++) if (vs[j].adm & (1u << k)) slot[vs[j].base + (k >> 2) * sx + ((k >> 1) & 1) * sy + (k & 1)] = -2;
+      for (int k = 0; k < 8; k++) if (vs[j].adm & (1u << k)) slot[vs[j].base + (k >> 2) * sx + ((k >> 1) & 1) * sy + (k & 1)] = MARK;
     __syncthreads();
     for (int i = tid; i < t.vol; i += nth) {   // compact
-      if (slot[i] == -2) { const int n = atomicAdd(&s_count, 1); slot[i] = n; if (n < NODE_CAP) list[n] = i; }
+      if (slot[i] == MARK) { const int n = atomicAdd(&s_count, 1); if (n < NODE_CAP) { slot[i] = (unsigned short)n; list[n] = (unsigned short)i; } }
     }
     __syncthreads();
     if (s_count > NODE_CAP) tiled = false;   // uniform: s_count is shared

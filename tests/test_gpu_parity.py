@@ -237,6 +237,46 @@ def test_ibm_phases_vs_oracle(orc, gpu):
     Lo.destroy(); Lg.destroy()
 
 
+@pytest.mark.parametrize("scale,which", [(1.2, "node list"), (1.5, "tile")])
+def test_ibm_oversized_cells_take_the_fallback_paths(orc, gpu, scale, which):
+    """the LDS-tiled spread / interpolate kernels hold one cell's stencil box (18^3 nodes) and node list (1536 nodes);
+    a cell blown up beyond either bound is handled by the per-vertex path inside the same kernels.  Both bounds are
+    crossed here and the result is checked against the oracle like the tiled path is."""
+    nx = ny = nz = 48
+    Po, Lo, Lg, So, hg = _sim_pair(orc, gpu, nx, ny, nz, (1, 1, 1), None)
+    assert _add_both(orc, So, hg, 0, (24.3, 23.6, 24.9), (30, 50, 10))
+    assert _add_both(orc, So, hg, 0, (2.0, 40.0, 12.0), (90, 0, 0))        # ordinary cell across the periodic seam
+    cf = hg.cellfields
+    pos, _, _ = _oracle_state(orc, So)
+    nv = 642
+    c0 = pos[:nv].mean(0)
+    pos[:nv] = c0 + scale * (pos[:nv] - c0)
+    b = np.floor(pos[:nv]).astype(int)
+    ext = b.max(0) - b.min(0) + 2
+    nodes = len({tuple(r + np.array(d)) for r in b for d in np.ndindex(2, 2, 2)})
+    if which == "tile":
+        assert ext.prod() > 5832
+    else:
+        assert ext.prod() <= 5832 and nodes > 1536
+    rng = np.random.default_rng(11)
+    frc = 1e-4 * rng.standard_normal(pos.shape)
+    orc.orc_sim_set(So, 0, O.dptr(pos)); cf.positions = pos
+    orc.orc_sim_set(So, 2, O.dptr(frc)); cf.forces = frc
+    F = (1e-6, 2e-6, -1e-6)
+    Lo.set_force_uniform(F); Lg.setExternalVector(F)
+    f0 = _random_populations(rng, nx * ny * nz, 0.01)
+    Lo.f[:] = f0; Lg.set_populations(f0)
+    orc.orc_sim_spread(So); cf.spreadParticleForce(True)
+    Fo = Lo.force.copy() - np.array(F)[None, :]
+    Fg = Lg.ibm_force()
+    assert np.abs(Fg - Fo).max() <= 1e-14 * np.abs(Fo).max()
+    orc.orc_collide_stream(Lo.ptr); Lg.collideAndStream(1)
+    orc.orc_sim_interpolate(So); cf.interpolateFluidVelocity()
+    _, v_o, _ = _oracle_state(orc, So)
+    assert np.abs(cf.velocities - v_o).max() <= 1e-13 * np.abs(v_o).max()
+    Lo.destroy(); Lg.destroy()
+
+
 @pytest.mark.parametrize("case", ["pipe_rbc", "pipe_rbc_plt_cadence", "box_periodic"])
 def test_iterate_trajectories_vs_oracle(orc, gpu, case):
     """HemoCell::iterate for N steps: fluid populations and vertex positions within 1e-6 relative of the

@@ -75,6 +75,7 @@ void orc_lattice_init_equilibrium(orc_lattice *L, double rho, const double u[3])
  * examples/pipeflow/pipeflow.cpp:144-146) */
 void orc_lattice_set_force_uniform(orc_lattice *L, const double F[3]) {
   long n = (long)L->nx * L->ny * L->nz;
+#pragma omp parallel for num_threads(L->nthreads) schedule(static) if (L->nthreads > 1)
   for (long k = 0; k < n; k++) { L->force[3 * k] = F[0]; L->force[3 * k + 1] = F[1]; L->force[3 * k + 2] = F[2]; }
 }
 
@@ -877,6 +878,10 @@ int orc_sim_add_cell(orc_sim *S, int type, const double centre_lu[3], const doub
 /* HemoCellParticleField::spreadParticleForce, core/hemoCellParticleField.cpp:841-863 */
 void orc_sim_spread(orc_sim *S) {
   orc_lattice *L = S->L;
+  /* with more than one thread (CPU-baseline timing only) the additions become atomic and their order is no
+   * longer the reference's; the parity tests run this loop on one thread */
+  const int par = L->nthreads > 1;
+#pragma omp parallel for num_threads(L->nthreads) schedule(static) if (par)
   for (long p = 0; p < S->np; p++) {
     orc_particle *pt = S->particles + p;
     long *nodes = S->st_nodes + 8 * p; double *w = S->st_w + 8 * p;
@@ -886,13 +891,20 @@ void orc_sim_spread(orc_sim *S) {
       if (mag > S->P.f_limit) { double s = S->P.f_limit / mag; pt->force[0] *= s; pt->force[1] *= s; pt->force[2] *= s; }
     }
     for (int j = 0; j < S->st_n[p]; j++)
-      for (int d = 0; d < 3; d++) L->force[3 * nodes[j] + d] += ((pt->force_repulsion[d] + pt->force[d]) * w[j]);
+      for (int d = 0; d < 3; d++) {
+        const double add = ((pt->force_repulsion[d] + pt->force[d]) * w[j]);
+        if (par) {
+#pragma omp atomic
+          L->force[3 * nodes[j] + d] += add;
+        } else L->force[3 * nodes[j] + d] += add;
+      }
   }
 }
 
 /* HemoCellParticleField::interpolateFluidVelocity, core/hemoCellParticleField.cpp:819-839:
  * reuses the stencil cached by the spread of the same iteration (:827) */
 void orc_sim_interpolate(orc_sim *S) {
+#pragma omp parallel for num_threads(S->L->nthreads) schedule(static) if (S->L->nthreads > 1)
   for (long p = 0; p < S->np; p++) {
     orc_particle *pt = S->particles + p;
     double vel[3] = {0.0, 0.0, 0.0};
@@ -921,6 +933,7 @@ static void delete_cell(orc_sim *S, int type, long cell) {
  * removes it, which leaves an incomplete cell that no longer receives
  * mechanics; here the whole cell is removed at once (documented in DESIGN.md). */
 void orc_sim_advance(orc_sim *S) {
+#pragma omp parallel for num_threads(S->L->nthreads) schedule(static) if (S->L->nthreads > 1)
   for (long p = 0; p < S->np; p++) {
     orc_particle *pt = S->particles + p;
     for (int d = 0; d < 3; d++) pt->position[d] += pt->v[d];
@@ -947,15 +960,21 @@ void orc_sim_mechanics(orc_sim *S, int forced) {
     const orc_celltype *T = S->types[t];
     if (!(S->iter % T->timescale == 0 || forced)) continue;
     const long nv = T->nv;
-    double *pos = (double *)malloc(sizeof(double) * 3 * (size_t)nv), *vel = (double *)malloc(sizeof(double) * 3 * (size_t)nv),
-           *frc = (double *)malloc(sizeof(double) * 3 * (size_t)nv);
-    for (long c = 0; c < S->ncells[t]; c++) {
-      orc_particle *cp = S->particles + orc_sim_type_offset(S, t) + c * nv;
-      for (long i = 0; i < nv; i++) for (int d = 0; d < 3; d++) { pos[3 * i + d] = cp[i].position[d]; vel[3 * i + d] = cp[i].v[d]; frc[3 * i + d] = 0.0; }
-      orc_cell_forces(T, pos, vel, frc, NULL, 0x1f);
-      for (long i = 0; i < nv; i++) for (int d = 0; d < 3; d++) cp[i].force[d] = frc[3 * i + d];
+    const long off = orc_sim_type_offset(S, t);
+    /* cells are independent: one cell per thread changes no result */
+#pragma omp parallel num_threads(S->L->nthreads) if (S->L->nthreads > 1)
+    {
+      double *pos = (double *)malloc(sizeof(double) * 3 * (size_t)nv), *vel = (double *)malloc(sizeof(double) * 3 * (size_t)nv),
+             *frc = (double *)malloc(sizeof(double) * 3 * (size_t)nv);
+#pragma omp for schedule(static)
+      for (long c = 0; c < S->ncells[t]; c++) {
+        orc_particle *cp = S->particles + off + c * nv;
+        for (long i = 0; i < nv; i++) for (int d = 0; d < 3; d++) { pos[3 * i + d] = cp[i].position[d]; vel[3 * i + d] = cp[i].v[d]; frc[3 * i + d] = 0.0; }
+        orc_cell_forces(T, pos, vel, frc, NULL, 0x1f);
+        for (long i = 0; i < nv; i++) for (int d = 0; d < 3; d++) cp[i].force[d] = frc[3 * i + d];
+      }
+      free(pos); free(vel); free(frc);
     }
-    free(pos); free(vel); free(frc);
   }
 }
 

@@ -82,6 +82,8 @@ SIGNATURES = {
     "hcp_set_repulsion": (C.c_int, [VP, C.c_double, C.c_double, C.c_int]),
     "hcp_repulsion": (C.c_int, [VP]),
     "hcp_download_repulsion": (C.c_int, [VP, c_double_p]),
+    "hcp_set_boundary_repulsion": (C.c_int, [VP, C.c_double, C.c_double, C.c_int]),
+    "hcp_boundary_repulsion": (C.c_int, [VP]),
     "hcp_spread": (C.c_int, [VP, C.c_int]),
     "hcp_interpolate": (C.c_int, [VP]),
     "hcp_advance": (C.c_int, [VP, C.c_int]),

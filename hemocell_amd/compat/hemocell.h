@@ -331,7 +331,11 @@ class HemoCell {
     hlog << "(HemoCell) (Repulsion Timescale Seperation) Setting seperation to " << separation << " timesteps" << endl;
     repulsionTimescale = separation; repulsionPushed = false;
   }
-  void enableBoundaryParticles(T, T, unsigned int = 1) { hlog << "(HemoCell) boundary particles are not available in the GPU back end yet" << endl; std::exit(1); }
+  void enableBoundaryParticles(T boundaryRepulsionConstant, T boundaryRepulsionCutoff, unsigned int timestep = 1) {   // core/hemoCell.cpp:428-436
+    hlog << "(HemoCell) (Repulsion) Setting boundary repulsion constant to " << boundaryRepulsionConstant << ". boundary repulsionCutoff to" << boundaryRepulsionCutoff << " µm" << endl;
+    boundaryRepulsionConstant_ = boundaryRepulsionConstant; boundaryRepulsionCutoff_ = boundaryRepulsionCutoff * (1e-6 / Parameters::dx);
+    boundaryRepulsionTimescale = timestep; boundaryRepulsionEnabled = true; boundaryRepulsionPushed = false;
+  }
   void setInitialMinimumDistanceFromSolid(string name, T distance) {   // core/hemoCell.cpp:410-418 (micrometres, stored as unsigned int)
     (*cellfields)[name]->minimumDistanceFromSolid = (unsigned int)distance;
   }
@@ -343,6 +347,7 @@ class HemoCell {
   void writeOutput();
   void iterate() {
     hc_cells *c = cellfields->device();
+    if (boundaryRepulsionEnabled && !boundaryRepulsionPushed) { hc_check(hcp_set_boundary_repulsion(c, boundaryRepulsionConstant_, boundaryRepulsionCutoff_, (int)boundaryRepulsionTimescale), "hcp_set_boundary_repulsion"); boundaryRepulsionPushed = true; }
     if (repulsionEnabled && !repulsionPushed) { hc_check(hcp_set_repulsion(c, repulsionConstant_, repulsionCutoff_, (int)repulsionTimescale), "hcp_set_repulsion"); repulsionPushed = true; }
     long it = iter;
     hc_check(hc_iterate(lattice->device(), c, &it, 1, (int)cellfields->particleVelocityUpdateTimescale, /*force_limit=*/1, /*deletion check=*/1), "iterate");
@@ -352,6 +357,7 @@ class HemoCell {
 
   bool outputInSiUnits = true;
   bool repulsionEnabled = false, repulsionPushed = false; T repulsionConstant_ = 0, repulsionCutoff_ = 0; unsigned int repulsionTimescale = 1;
+  bool boundaryRepulsionEnabled = false, boundaryRepulsionPushed = false; T boundaryRepulsionConstant_ = 0, boundaryRepulsionCutoff_ = 0; unsigned int boundaryRepulsionTimescale = 1;
   MultiBlockLattice3D<T, DESCRIPTOR> *lattice = nullptr;
   Config *cfg = nullptr;
   HemoCellFields *cellfields = nullptr;

@@ -62,6 +62,9 @@ struct hc_cells {
   // vertex-vertex repulsion (core/hemoCellParticleField.cpp:677-743); arrays exist only once it is enabled
   double *rep[3] = {nullptr, nullptr, nullptr};
   int rep_enabled = 0, rep_timescale = 1; double rep_const = 0, rep_cutoff = 0;
+  // boundary particles (core/hemoCellParticleField.cpp:865-918): flag map of the wall nodes that repel vertices
+  int brep_enabled = 0, brep_timescale = 1; double brep_const = 0, brep_cutoff = 0; uint8_t *d_bflag = nullptr;
+  bool rep_on() const { return rep_enabled || brep_enabled; }
   unsigned int *d_keys[2] = {nullptr, nullptr}; int *d_vals[2] = {nullptr, nullptr}; void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0; long sort_cap = 0;
   int *d_iscratch[2] = {nullptr, nullptr};   // staged slot lists of the envelope exchange (stream ordered, no sync)
   size_t iscratch_cap[2] = {0, 0};
@@ -939,6 +942,41 @@ __global__ __launch_bounds__(256) void rep_force_kernel(LatView v, long cap, lon
   rx[i] = a0; ry[i] = a1; rz[i] = a2;
 }
 
+// Boundary particles (core/hemoCellParticleField.cpp:865-918): every flagged wall node pushes the vertices binned in
+// the 27 bins around it with k * (cutoff / d) along their separation.  Gather form: each vertex visits the 27 nodes
+// around its own bin in ascending (x, y, z) order -- the order in which the reference's x-major list of boundary
+// particles reaches it -- and ADDS to force_repulsion (only applyRepulsionForce ever zeroes it, :703).
+__global__ __launch_bounds__(256) void boundary_rep_kernel(LatView v, long n, const uint8_t *bflag, const double *px, const double *py, const double *pz,
+                                                           double *rx, double *ry, double *rz, double br_const, double br_cutoff) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double x = px[i], y = py[i], z = pz[i];
+  const long cx = nearest_node(x), cy = nearest_node(y), cz = nearest_node(z);
+  if ((cy < 0 || cy >= v.ny) && !v.per_y) return;   // not in the particle grid (update_pg, :158-161)
+  if ((cz < 0 || cz >= v.nz) && !v.per_z) return;
+  if (!v.wrap_x) { const long lx = cx - v.x0; if (v.halo_x ? (lx < -HALO || lx >= v.nx + HALO) : (lx < 0 || lx >= v.nx)) return; }
+  double a0 = rx[i], a1 = ry[i], a2 = rz[i];
+  for (int dx = -1; dx <= 1; dx++)
+    for (int dy = -1; dy <= 1; dy++)
+      for (int dz = -1; dz <= 1; dz++) {
+        const long gx = cx + dx, gy = cy + dy, gz = cz + dz;
+        long lx = gx - v.x0, ly = gy, lz = gz;
+        if (v.wrap_x) lx = pmod(lx, v.nx);
+        else if (v.halo_x) { if (lx < -HALO || lx >= v.nx + HALO) continue; }
+        else if (lx < 0 || lx >= v.nx) continue;
+        if (ly < 0 || ly >= v.ny) { if (v.per_y) ly = pmod(ly, v.ny); else continue; }
+        if (lz < 0 || lz >= v.nz) { if (v.per_z) lz = pmod(lz, v.nz); else continue; }
+        if (!bflag[(lx + HALO) * (long)v.plane + ly * v.nz + lz]) continue;
+        const double d0 = x - (double)gx, d1 = y - (double)gy, d2 = z - (double)gz;
+        const double dist = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        if (dist < br_cutoff) {
+          const double m = br_const * (1 / (dist / br_cutoff));
+          a0 = a0 + m * (d0 / dist); a1 = a1 + m * (d1 / dist); a2 = a2 + m * (d2 / dist);
+        }
+      }
+  rx[i] = a0; ry[i] = a1; rz[i] = a2;
+}
+
 __global__ void fill_vert_cell_kernel(long n, int nv, int cell0, long first, int *vert_cell) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -1010,7 +1048,7 @@ static int sync_to_device(hc_cells *C) {
       HC_HIP(hipMalloc((void **)&C->frc[d], C->cap * sizeof(double)));
     }
     HC_HIP(hipMalloc((void **)&C->d_vert_cell, C->cap * sizeof(int)));
-    if (C->rep_enabled) for (int d = 0; d < 3; d++) { HC_HIP(hipMalloc((void **)&C->rep[d], C->cap * sizeof(double))); HC_HIP(hipMemset(C->rep[d], 0, C->cap * sizeof(double))); }
+    if (C->rep_on()) for (int d = 0; d < 3; d++) { HC_HIP(hipMalloc((void **)&C->rep[d], C->cap * sizeof(double))); HC_HIP(hipMemset(C->rep[d], 0, C->cap * sizeof(double))); }
     C->tag_cap = capcells + 1;
     HC_HIP(hipMalloc((void **)&C->d_tag, C->tag_cap * sizeof(int)));
     for (int t = 0; t < C->ntypes; t++) {
@@ -1186,6 +1224,7 @@ int hcp_destroy(hc_cells *C) {
   free_device_arrays(C);
   if (C->h_ntag) hipHostFree(C->h_ntag);
   if (C->d_ntag) hipFree(C->d_ntag);
+  if (C->d_bflag) hipFree(C->d_bflag);
   for (int k = 0; k < 2; k++) if (C->d_iscratch[k]) hipFree(C->d_iscratch[k]);
   delete C;
   return HC_OK;
@@ -1355,7 +1394,7 @@ int hcp_spread(hc_cells *C, int force_limit) {
     const long n = C->ncells[t] * C->types[t]->host.nv, f = C->first[t];
     if (n == 0) continue;
     const int nv = C->types[t]->host.nv;
-    const double *rp[3] = {C->rep_enabled ? C->rep[0] + f : nullptr, C->rep_enabled ? C->rep[1] + f : nullptr, C->rep_enabled ? C->rep[2] + f : nullptr};
+    const double *rp[3] = {C->rep_on() ? C->rep[0] + f : nullptr, C->rep_on() ? C->rep[1] + f : nullptr, C->rep_on() ? C->rep[2] + f : nullptr};
     if (g_ibm_per_vertex)
       hipLaunchKernelGGL(ibm_spread_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), v, n,
                          (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
@@ -1501,6 +1540,7 @@ int hc_iterate(hc_lattice *L, hc_cells *C, long *iter, int n, int particle_times
   for (int s = 0; s < n; s++) {
     const long it = *iter;
     if (C->rep_enabled && it % C->rep_timescale == 0) { if ((rc = hcp_repulsion(C)) != HC_OK) return rc; }   // core/hemoCell.cpp:307-309
+    if (C->brep_enabled && it % C->brep_timescale == 0) { if ((rc = hcp_boundary_repulsion(C)) != HC_OK) return rc; }   // :310-312
     if ((rc = hcp_spread(C, force_limit)) != HC_OK) return rc;                  // :313
     if ((rc = hcl_collide_stream_part(L, 0)) != HC_OK) return rc;               // :317
     hcl_step_end(L);
@@ -1706,6 +1746,67 @@ int hcp_repulsion(hc_cells *C) {
                      (const int *)C->d_vals[1], (const int *)C->d_vert_cell, (const double *)C->pos[0], (const double *)C->pos[1], (const double *)C->pos[2],
                      C->rep[0], C->rep[1], C->rep[2], C->rep_const, C->rep_cutoff);
   HC_HIP(hipGetLastError());
+  return HC_OK;
+}
+
+// hemocell.enableBoundaryParticles(k, cutoff_um, timestep) (core/hemoCell.cpp:428-436): populateBoundaryParticles
+// (core/hemoCellParticleField.cpp:865-890) becomes a flag map -- wall nodes with a non-wall node among their 26
+// neighbours -- built from the host mask (halo planes included; neighbours beyond them count as unknown = wall)
+int hcp_set_boundary_repulsion(hc_cells *C, double br_const, double br_cutoff_lu, int timescale) {
+  HC_REQUIRE(C && br_cutoff_lu > 0 && timescale >= 1, "hcp_set_boundary_repulsion: bad arguments");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  const hc_lattice *L = C->L;
+  const int NX = L->nx + 2 * HALO, ny = L->ny, nz = L->nz;
+  const bool wrap_x = L->n_slabs == 1 && L->periodic[0];
+  std::vector<uint8_t> flag(L->npad, 0);
+  auto solid = [&](int xp, int y, int z, bool &known) -> bool {   // xp = padded x
+    known = true;
+    if (wrap_x) { int lx = xp - HALO; lx = ((lx % L->nx) + L->nx) % L->nx; xp = lx + HALO; }
+    else if (xp < 0 || xp >= NX) { known = false; return true; }
+    if (L->n_slabs == 1 && !L->periodic[0] && (xp < HALO || xp >= HALO + L->nx)) { known = false; return true; }   // outside the domain
+    if (y < 0 || y >= ny) { if (L->periodic[1]) y = (y + ny) % ny; else { known = false; return true; } }
+    if (z < 0 || z >= nz) { if (L->periodic[2]) z = (z + nz) % nz; else { known = false; return true; } }
+    return L->hmask[((size_t)xp * ny + y) * nz + z] != 0;
+  };
+  for (int xp = 0; xp < NX; xp++)
+    for (int y = 0; y < ny; y++)
+      for (int z = 0; z < nz; z++) {
+        bool known;
+        if (L->n_slabs == 1 && (xp < HALO || xp >= HALO + L->nx)) continue;   // single slab: halo planes are never addressed
+        if (!solid(xp, y, z, known)) continue;
+        bool near = false;
+        for (int a = -1; a <= 1 && !near; a++) for (int b = -1; b <= 1 && !near; b++) for (int c = -1; c <= 1; c++) {
+          bool k2; const bool s2 = solid(xp + a, y + b, z + c, k2);
+          if (k2 && !s2) { near = true; break; }
+        }
+        if (near) flag[((size_t)xp * ny + y) * nz + z] = 1;
+      }
+  if (!C->d_bflag) HC_HIP(hipMalloc((void **)&C->d_bflag, L->npad));
+  HC_HIP(hipMemcpy(C->d_bflag, flag.data(), L->npad, hipMemcpyHostToDevice));
+  C->brep_const = br_const; C->brep_cutoff = br_cutoff_lu; C->brep_timescale = timescale;
+  if (!C->brep_enabled) {
+    C->brep_enabled = 1;
+    if (C->cap > 0 && !C->rep[0]) for (int d = 0; d < 3; d++) { HC_HIP(hipMalloc((void **)&C->rep[d], C->cap * sizeof(double))); HC_HIP(hipMemset(C->rep[d], 0, C->cap * sizeof(double))); }
+  }
+  return HC_OK;
+}
+
+// cellfields->applyBoundaryRepulsionForce() (core/hemoCell.cpp:310-312 -> core/hemoCellParticleField.cpp:891-918)
+int hcp_boundary_repulsion(hc_cells *C) {
+  HC_REQUIRE(C, "hcp_boundary_repulsion: null pointer");
+  HC_REQUIRE(C->brep_enabled, "hcp_boundary_repulsion: call hcp_set_boundary_repulsion first");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  if (C->nverts == 0) return HC_OK;
+  if (!C->rep[0]) for (int d = 0; d < 3; d++) { HC_HIP(hipMalloc((void **)&C->rep[d], C->cap * sizeof(double))); HC_HIP(hipMemset(C->rep[d], 0, C->cap * sizeof(double))); }
+  const LatView v = make_view(C->L);
+  for (int t = 0; t < C->ntypes; t++) {
+    const long n = C->ncells[t] * C->types[t]->host.nv, f = C->first[t];
+    if (n == 0) continue;
+    hipLaunchKernelGGL(boundary_rep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), v, n, (const uint8_t *)C->d_bflag,
+                       (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
+                       C->rep[0] + f, C->rep[1] + f, C->rep[2] + f, C->brep_const, C->brep_cutoff);
+    HC_HIP(hipGetLastError());
+  }
   return HC_OK;
 }
 

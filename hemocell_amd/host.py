@@ -274,6 +274,13 @@ class Cells:
     def applyRepulsionForce(self):
         check(self.lib.hcp_repulsion(self.ptr))
 
+    def enableBoundaryParticles(self, br_const, br_cutoff_um, timescale=1):
+        """hemocell.enableBoundaryParticles(k, cutoff [um], timestep) (core/hemoCell.cpp:428-436)"""
+        check(self.lib.hcp_set_boundary_repulsion(self.ptr, float(br_const), float(br_cutoff_um) * (1e-6 / self.P.dx), int(timescale)))
+
+    def applyBoundaryRepulsionForce(self):
+        check(self.lib.hcp_boundary_repulsion(self.ptr))
+
     @property
     def repulsion_forces(self):
         out = np.empty((self.counts()[0], 3), dtype=np.float64)

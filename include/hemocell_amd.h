@@ -161,6 +161,13 @@ int hcp_add_vertex_force(hc_cells *C, const long *vertex_index, int n, const dou
 int hcp_set_repulsion(hc_cells *C, double r_const, double r_cutoff_lu, int timescale);
 int hcp_repulsion(hc_cells *C);
 int hcp_download_repulsion(hc_cells *C, double *out /*[n][3]*/);
+/* hemocell.enableBoundaryParticles(k, cutoff, timestep) (core/hemoCell.cpp:428-436): wall nodes with a non-wall node
+ * among their 26 neighbours (populateBoundaryParticles, core/hemoCellParticleField.cpp:865-890) push the vertices
+ * binned around them; hcp_boundary_repulsion is cellfields->applyBoundaryRepulsionForce() (core/hemoCell.cpp:310-312 ->
+ * core/hemoCellParticleField.cpp:891-918) and ADDS to force_repulsion, which only hcp_repulsion resets (:703).
+ * hc_iterate applies it every `timescale` iterations.  Call after hcl_set_mask. */
+int hcp_set_boundary_repulsion(hc_cells *C, double br_const, double br_cutoff_lu, int timescale);
+int hcp_boundary_repulsion(hc_cells *C);
 /* cellfields->spreadParticleForce() (core/hemoCell.cpp:313 -> core/hemoCellParticleField.cpp:841-863) */
 int hcp_spread(hc_cells *C, int force_limit);
 /* cellfields->interpolateFluidVelocity() (core/hemoCell.cpp:329 -> core/hemoCellParticleField.cpp:819-839) */

@@ -783,6 +783,7 @@ orc_sim *orc_sim_create(orc_lattice *L, const orc_params *P) {
   S->particle_velocity_timescale = 1;
   S->force_limit_enabled = 1;
   S->rep_enabled = 0; S->rep_timescale = 1;
+  S->brep_enabled = 0; S->brep_timescale = 1;
   return S;
 }
 void orc_sim_destroy(orc_sim *S) {
@@ -1057,10 +1058,55 @@ void orc_sim_repulsion(orc_sim *S, double r_const, double r_cutoff) {
   free(head); free(tail); free(next);
 }
 
+/* Boundary particles: HemoCellParticleField::populateBoundaryParticles (core/hemoCellParticleField.cpp:865-890) makes
+ * one of every boundary node that has a non-boundary node among its 26 neighbours; applyBoundaryRepulsionForce
+ * (:891-918) lets each push the vertices binned (update_pg, nearest node) in the 27 bins around it:
+ *   force_repulsion += k * (1 / (dist / cutoff)) * (dv / dist)   for dist < cutoff, dv = x_vertex - x_node.
+ * Restated per vertex: the 27 nodes around the vertex's bin in ascending (x, y, z) order, which is the order in
+ * which the reference's boundaryParticles list (built x-major) reaches that vertex.  One global block: nodes wrap in
+ * periodic directions (the reference's loops run over a block with its periodic envelope).  force_repulsion is
+ * only ever zeroed by applyRepulsionForce (:703), so without vertex-vertex repulsion it accumulates, as it does
+ * in the reference. */
+static int is_boundary_particle(const orc_lattice *L, long x, long y, long z) {
+  int inside;
+  if (!node_is_boundary_abs(L, x, y, z, &inside) || !inside) return 0;
+  for (int a = -1; a <= 1; a++) for (int b = -1; b <= 1; b++) for (int c = -1; c <= 1; c++) {
+    int in2;
+    const int m = node_is_boundary_abs(L, x + a, y + b, z + c, &in2);
+    if (in2 && !m) return 1;
+  }
+  return 0;
+}
+void orc_sim_boundary_repulsion(orc_sim *S, double br_const, double br_cutoff) {
+  const orc_lattice *L = S->L;
+  const int dims[3] = {L->nx, L->ny, L->nz};
+  for (long p = 0; p < S->np; p++) {
+    orc_particle *pt = S->particles + p;
+    long c[3]; int ok = 1;
+    for (int d = 0; d < 3; d++) {
+      c[d] = (long)floor(pt->position[d] + 0.5);
+      if ((c[d] < 0 || c[d] >= dims[d]) && !L->periodic[d]) ok = 0;   /* not in the particle grid (:158-161) */
+    }
+    if (!ok) continue;
+    for (int a = -1; a <= 1; a++) for (int b = -1; b <= 1; b++) for (int e = -1; e <= 1; e++) {
+      const long n[3] = {c[0] + a, c[1] + b, c[2] + e};
+      if (!is_boundary_particle(L, n[0], n[1], n[2])) continue;
+      double dv[3]; for (int d = 0; d < 3; d++) dv[d] = pt->position[d] - (double)n[d];
+      const double distance = sqrt(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+      if (distance < br_cutoff)
+        for (int d = 0; d < 3; d++) {
+          const double rfm = br_const * (1 / (distance / br_cutoff)) * (dv[d] / distance);
+          pt->force_repulsion[d] = pt->force_repulsion[d] + rfm;
+        }
+    }
+  }
+}
+
 /* HemoCell::iterate, core/hemoCell.cpp:299-376, followed by the driver's
  * setExternalVector(body force) (examples/pipeflow/pipeflow.cpp:144-146) */
 void orc_sim_iterate(orc_sim *S) {
   if (S->rep_enabled && S->iter % S->rep_timescale == 0) orc_sim_repulsion(S, S->rep_const, S->rep_cutoff);   /* :307-309 */
+  if (S->brep_enabled && S->iter % S->brep_timescale == 0) orc_sim_boundary_repulsion(S, S->brep_const, S->brep_cutoff);   /* :310-312 */
   orc_sim_spread(S);                                            /* :313 */
   orc_collide_stream(S->L);                                     /* :317 */
   if (S->iter % S->particle_velocity_timescale == 0) orc_sim_interpolate(S); /* :327-332 */

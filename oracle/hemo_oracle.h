@@ -132,6 +132,7 @@ typedef struct orc_sim {
   long cells_deleted;
   double body_force[3];     /* driver's setExternalVector after each iterate */
   int rep_enabled, rep_timescale; double rep_const, rep_cutoff;   /* setRepulsion / setRepulsionTimeScaleSeperation */
+  int brep_enabled, brep_timescale; double brep_const, brep_cutoff;   /* enableBoundaryParticles (core/hemoCell.cpp:428-436) */
 } orc_sim;
 
 orc_sim *orc_sim_create(orc_lattice *L, const orc_params *P);
@@ -147,6 +148,7 @@ void orc_sim_advance(orc_sim *S);
 void orc_sim_mechanics(orc_sim *S, int forced);
 void orc_sim_iterate(orc_sim *S);
 void orc_sim_repulsion(orc_sim *S, double r_const, double r_cutoff_lu);
+void orc_sim_boundary_repulsion(orc_sim *S, double br_const, double br_cutoff_lu);
 long orc_sim_type_offset(const orc_sim *S, int type);
 /* what: 0 position, 1 velocity, 2 force, 3 force_repulsion; arrays [np][3] */
 void orc_sim_get(const orc_sim *S, int what, double *out);

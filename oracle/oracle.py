@@ -61,7 +61,8 @@ class Sim(C.Structure):
                 ("st_nodes", c_long_p), ("st_w", c_double_p), ("st_n", c_int_p),
                 ("particle_velocity_timescale", C.c_int), ("force_limit_enabled", C.c_int),
                 ("iter", C.c_long), ("cells_deleted", C.c_long), ("body_force", C.c_double * 3),
-                ("rep_enabled", C.c_int), ("rep_timescale", C.c_int), ("rep_const", C.c_double), ("rep_cutoff", C.c_double)]
+                ("rep_enabled", C.c_int), ("rep_timescale", C.c_int), ("rep_const", C.c_double), ("rep_cutoff", C.c_double),
+                ("brep_enabled", C.c_int), ("brep_timescale", C.c_int), ("brep_const", C.c_double), ("brep_cutoff", C.c_double)]
 
 
 def build():
@@ -101,6 +102,7 @@ def load():
         "orc_sim_mechanics": (None, [SP, C.c_int]),
         "orc_sim_iterate": (None, [SP]),
         "orc_sim_repulsion": (None, [SP, C.c_double, C.c_double]),
+        "orc_sim_boundary_repulsion": (None, [SP, C.c_double, C.c_double]),
         "orc_sim_type_offset": (C.c_long, [SP, C.c_int]),
         "orc_sim_get": (None, [SP, C.c_int, c_double_p]),
         "orc_sim_set": (None, [SP, C.c_int, c_double_p]),

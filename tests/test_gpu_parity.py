@@ -542,3 +542,43 @@ def test_repulsion_vs_oracle(orc, gpu):
     orc.orc_sim_get(So, 3, O.dptr(r_o))
     assert np.abs(hg.cellfields.repulsion_forces - r_o).max() <= 1e-9 * max(np.abs(r_o).max(), 1e-30)
     Lo.destroy(); Lg.destroy()
+
+
+def test_boundary_particle_repulsion_vs_oracle(orc, gpu):
+    """enableBoundaryParticles (core/hemoCell.cpp:428-436, core/hemoCellParticleField.cpp:865-918): wall nodes next
+    to the fluid push nearby vertices.  An RBC close to the pipe wall and one straddling the periodic seam near the
+    wall: force_repulsion vs the oracle (bit for bit: same visiting order), its accumulation over a second call
+    (only applyRepulsionForce resets it), then 30 coupled iterations with both repulsions on."""
+    nx, ny, nz = 40, 34, 34
+    mask, R = gpu.pipe_mask(nx, ny, nz)
+    Po, Lo, Lg, So, hg = _sim_pair(orc, gpu, nx, ny, nz, (1, 0, 0), mask)
+    assert _add_both(orc, So, hg, 0, (14.0, 16.5, 4.6), (90, 0, 0))       # flat against the wall, ~1.3 lu off it
+    assert _add_both(orc, So, hg, 0, (38.5, 16.5, 28.6), (90, 0, 0))      # other side, across the seam
+    assert _add_both(orc, So, hg, 0, (26.0, 16.5, 16.5), (0, 0, 0))       # mid-stream: feels nothing
+    k_b, cutoff_um = 3e-6, 1.0
+    cutoff = cutoff_um * (1e-6 / Po.dx)
+    cf = hg.cellfields
+    cf.enableBoundaryParticles(k_b, cutoff_um, 2)
+    So.contents.brep_enabled = 1; So.contents.brep_timescale = 2; So.contents.brep_const = k_b; So.contents.brep_cutoff = cutoff
+    r_o = np.zeros((So.contents.np, 3))
+    for calls in (1, 2):
+        orc.orc_sim_boundary_repulsion(So, k_b, cutoff); cf.applyBoundaryRepulsionForce()
+        orc.orc_sim_get(So, 3, O.dptr(r_o))
+        r_g = cf.repulsion_forces
+        assert np.array_equal(r_g, r_o), np.abs(r_g - r_o).max()
+    touched = np.abs(r_o).sum(1) > 0
+    assert touched[:642].sum() > 20 and touched[642:1284].sum() > 20 and touched[1284:].sum() == 0
+    # pushes away from the wall: towards the axis for the first cell (z small -> +z)
+    assert r_o[:642][touched[:642], 2].min() > 0
+    # coupled run, vertex-vertex repulsion on as well so that force_repulsion is reset every 2nd iteration
+    cf.setRepulsion(2e-6, 0.7, 2)
+    So.contents.rep_enabled = 1; So.contents.rep_timescale = 2; So.contents.rep_const = 2e-6; So.contents.rep_cutoff = 0.7 * (1e-6 / Po.dx)
+    orc.orc_sim_mechanics(So, 1); cf.applyConstitutiveModel(0, True)
+    for _ in range(30):
+        orc.orc_sim_iterate(So)
+    hg.iterate(30)
+    p_o, v_o, f_o = _oracle_state(orc, So)
+    assert np.abs(cf.positions - p_o).max() <= 1e-9
+    orc.orc_sim_get(So, 3, O.dptr(r_o))
+    assert np.abs(cf.repulsion_forces - r_o).max() <= 1e-9 * max(np.abs(r_o).max(), 1e-30)
+    Lo.destroy(); Lg.destroy()

@@ -830,20 +830,22 @@ __global__ __launch_bounds__(256) void cell_extent_kernel(int nv, const double *
 
 struct VertArrays { double *p[3], *v[3], *f[3], *r[3]; };   // r: repulsion force arrays or null
 
-// record layout per vertex: pos[3] vel[3] force[3] (the fields of serializeValues_t that change, core/hemoCellParticle.h:45-63)
-__global__ __launch_bounds__(256) void pack_cells_kernel(int nv, const int *slots, VertArrays a, double *buf, double x_shift) {
+// record layout per vertex: pos[3] vel[3] force[3] and, once a repulsion is enabled (rec == 12), force_repulsion[3]
+// (the fields of serializeValues_t that change, core/hemoCellParticle.h:45-63)
+__global__ __launch_bounds__(256) void pack_cells_kernel(int nv, int rec, const int *slots, VertArrays a, double *buf, double x_shift) {
   const long src = (long)slots[blockIdx.x] * nv, dst = (long)blockIdx.x * nv;
   for (int i = threadIdx.x; i < nv; i += 256) {
-    double *r = buf + (dst + i) * 9;
+    double *r = buf + (dst + i) * rec;
     r[0] = a.p[0][src + i] + x_shift; r[1] = a.p[1][src + i]; r[2] = a.p[2][src + i];
     r[3] = a.v[0][src + i]; r[4] = a.v[1][src + i]; r[5] = a.v[2][src + i];
     r[6] = a.f[0][src + i]; r[7] = a.f[1][src + i]; r[8] = a.f[2][src + i];
+    if (rec == 12) { r[9] = a.r[0][src + i]; r[10] = a.r[1][src + i]; r[11] = a.r[2][src + i]; }
   }
 }
 
 // merge rule of HemoCellParticleField::addParticle (core/hemoCellParticleField.cpp:173-235): a local
 // particle wins over an incoming copy; "local" = its nearest lattice node lies in this slab
-__global__ __launch_bounds__(256) void unpack_cells_kernel(int nv, const int *slots, const int *is_new, VertArrays a, const double *buf,
+__global__ __launch_bounds__(256) void unpack_cells_kernel(int nv, int rec, const int *slots, const int *is_new, VertArrays a, const double *buf,
                                                            int x0, int nx) {
   const long dst = (long)slots[blockIdx.x] * nv, src = (long)blockIdx.x * nv;
   const bool fresh = is_new[blockIdx.x] != 0;
@@ -854,11 +856,11 @@ __global__ __launch_bounds__(256) void unpack_cells_kernel(int nv, const int *sl
       take = !(gx >= 0 && gx < nx);
     }
     if (take) {
-      const double *r = buf + (src + i) * 9;
+      const double *r = buf + (src + i) * rec;
       a.p[0][dst + i] = r[0]; a.p[1][dst + i] = r[1]; a.p[2][dst + i] = r[2];
       a.v[0][dst + i] = r[3]; a.v[1][dst + i] = r[4]; a.v[2][dst + i] = r[5];
       a.f[0][dst + i] = r[6]; a.f[1][dst + i] = r[7]; a.f[2][dst + i] = r[8];
-      if (fresh && a.r[0]) { a.r[0][dst + i] = 0.0; a.r[1][dst + i] = 0.0; a.r[2][dst + i] = 0.0; }   // until the next evaluation
+      if (rec == 12) { a.r[0][dst + i] = r[9]; a.r[1][dst + i] = r[10]; a.r[2][dst + i] = r[11]; }
     }
   }
 }
@@ -920,17 +922,20 @@ __global__ __launch_bounds__(256) void rep_force_kernel(LatView v, long cap, lon
       for (int dy = -1; dy <= 1; dy++)
         for (int dz = -1; dz <= 1; dz++) {
           long bx = lxp + dx, by = ly + dy, bz = lz + dz;
-          double sx = 0.0, sy = 0.0, sz = 0.0;   // minimum-image shift applied to the neighbour's position
-          if (v.wrap_x) { if (bx < HALO) { bx += v.nx; sx = -(double)v.nx; } else if (bx >= v.nx + HALO) { bx -= v.nx; sx = (double)v.nx; } }
+          if (v.wrap_x) { if (bx < HALO) bx += v.nx; else if (bx >= v.nx + HALO) bx -= v.nx; }
           else if (bx < 0 || bx >= v.nx + 2 * HALO) continue;
-          if (by < 0) { if (!v.per_y) continue; by += v.ny; sy = -(double)v.ny; } else if (by >= v.ny) { if (!v.per_y) continue; by -= v.ny; sy = (double)v.ny; }
-          if (bz < 0) { if (!v.per_z) continue; bz += v.nz; sz = -(double)v.nz; } else if (bz >= v.nz) { if (!v.per_z) continue; bz -= v.nz; sz = (double)v.nz; }
+          if (by < 0) { if (!v.per_y) continue; by += v.ny; } else if (by >= v.ny) { if (!v.per_y) continue; by -= v.ny; }
+          if (bz < 0) { if (!v.per_z) continue; bz += v.nz; } else if (bz >= v.nz) { if (!v.per_z) continue; bz -= v.nz; }
           const unsigned int nkey = (unsigned int)(bx * (long)v.plane + by * v.nz + bz);
           const double fac = (dx == 0 && dy == 0 && dz == 0) ? 2.0 : 1.0;
           for (long q = lower_bound_u32(keys, nsorted, nkey); q < nsorted && keys[q] == nkey; q++) {
             const int j = vals[q];
             if (j == i || vert_cell[j] == ci) continue;
-            const double d0 = x - (px[j] + sx), d1 = y - (py[j] + sy), d2 = z - (pz[j] + sz);
+            // positions are not re-wrapped when a cell crosses a periodic face: minimum image of the separation
+            double d0 = x - px[j], d1 = y - py[j], d2 = z - pz[j];
+            if (v.wrap_x) d0 = d0 - (double)v.nx * rint(d0 / (double)v.nx);
+            if (v.per_y) d1 = d1 - (double)v.ny * rint(d1 / (double)v.ny);
+            if (v.per_z) d2 = d2 - (double)v.nz * rint(d2 / (double)v.nz);
             const double dist = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
             if (dist < r_cutoff) {
               const double m = fac * (r_const * (1 / (dist / r_cutoff)));
@@ -1597,7 +1602,7 @@ int hcp_cell_extents(hc_cells *C, int type, double *minmax) {
 
 size_t hcp_record_doubles(const hc_cells *C, int type) {
   if (!C || type < 0 || type >= C->ntypes) return 0;
-  return (size_t)C->types[type]->host.nv * 9;
+  return (size_t)C->types[type]->host.nv * (C->rep_on() ? 12 : 9);
 }
 
 int hcp_pack_cells(hc_cells *C, int type, const int *slots, int n, double x_shift, double *dev_buf) {
@@ -1608,7 +1613,7 @@ int hcp_pack_cells(hc_cells *C, int type, const int *slots, int n, double x_shif
   for (int i = 0; i < n; i++) HC_REQUIRE(slots[i] >= 0 && slots[i] < C->ncells[type], "hcp_pack_cells: slot out of range");
   int *d_slots = nullptr;
   rc = stage_ints(C, 0, &d_slots, slots, n); if (rc != HC_OK) return rc;
-  hipLaunchKernelGGL(pack_cells_kernel, dim3((unsigned)n), dim3(256), 0, hc::stream(), C->types[type]->host.nv, (const int *)d_slots, vert_arrays(C, type), dev_buf, x_shift);
+  hipLaunchKernelGGL(pack_cells_kernel, dim3((unsigned)n), dim3(256), 0, hc::stream(), C->types[type]->host.nv, C->rep_on() ? 12 : 9, (const int *)d_slots, vert_arrays(C, type), dev_buf, x_shift);
   HC_HIP(hipGetLastError());
   return HC_OK;
 }
@@ -1639,7 +1644,7 @@ int hcp_unpack_cells(hc_cells *C, int type, const int *slots, const long *cell_i
   int *d_slots = nullptr, *d_new = nullptr;
   rc = stage_ints(C, 0, &d_slots, slots, n); if (rc != HC_OK) return rc;
   rc = stage_ints(C, 1, &d_new, is_new, n); if (rc != HC_OK) return rc;
-  hipLaunchKernelGGL(unpack_cells_kernel, dim3((unsigned)n), dim3(256), 0, hc::stream(), C->types[type]->host.nv, (const int *)d_slots, (const int *)d_new,
+  hipLaunchKernelGGL(unpack_cells_kernel, dim3((unsigned)n), dim3(256), 0, hc::stream(), C->types[type]->host.nv, C->rep_on() ? 12 : 9, (const int *)d_slots, (const int *)d_new,
                      vert_arrays(C, type), dev_buf, C->L->x0, C->L->nx);
   HC_HIP(hipGetLastError());
   return HC_OK;

@@ -13,6 +13,8 @@ Only point-to-point messages between x-neighbours are used (no collective on the
 written against a small engine interface so that it runs unchanged on the HIP engine (product) and on a
 numpy stand-in used by the CPU gloo tests of the protocol itself.
 """
+import ctypes as C
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -101,28 +103,29 @@ class HipEngine:
     def nv(self, t):
         return self.C.types[t].nv
 
+    def record_doubles(self, t):
+        """doubles per cell record: 9 per vertex, 12 once a repulsion is enabled (force_repulsion travels too)"""
+        return int(self.lib.hcp_record_doubles(self.C.ptr, t))
+
     def cell_ids(self, t):
         ids = self.C.cell_ids()
         f = sum(self.C.type_range(u)[1] for u in range(t))
         return ids[f:f + self.C.type_range(t)[1]]
 
     def cell_extents(self, t):
-        import ctypes as C
         n = self.C.type_range(t)[1]
         ext = np.empty((n, 3), dtype=np.float64)
         host.check(self.lib.hcp_cell_extents(self.C.ptr, t, host.dptr(ext)))
         return ext
 
     def pack_cells(self, t, slots, x_shift):
-        import ctypes as C
         slots = np.ascontiguousarray(slots, dtype=np.int32)
-        buf = torch.empty(len(slots) * self.nv(t) * 9, dtype=torch.float64, device=self.device)
+        buf = torch.empty(len(slots) * self.record_doubles(t), dtype=torch.float64, device=self.device)
         host.check(self.lib.hcp_pack_cells(self.C.ptr, t, slots.ctypes.data_as(host.capi.c_int_p), len(slots), float(x_shift),
                                            C.c_void_p(buf.data_ptr())))
         return buf
 
     def unpack_cells(self, t, slots, ids, is_new, buf):
-        import ctypes as C
         slots = np.ascontiguousarray(slots, dtype=np.int32)
         ids = np.ascontiguousarray(ids, dtype=np.int64)
         is_new = np.ascontiguousarray(is_new, dtype=np.int32)
@@ -134,7 +137,16 @@ class HipEngine:
         host.check(self.lib.hcp_remove_cells(self.C.ptr, t, slots.ctypes.data_as(host.capi.c_int_p), len(slots)))
 
     def record_buffer(self, t, n):
-        return torch.empty(n * self.nv(t) * 9, dtype=torch.float64, device=self.device)
+        return torch.empty(n * self.record_doubles(t), dtype=torch.float64, device=self.device)
+
+    def repulsion(self, it):
+        """core/hemoCell.cpp:307-312: vertex-vertex and boundary-particle repulsion at their own cadences"""
+        if self.C is None:
+            return
+        if self.C.rep_timescale and it % self.C.rep_timescale == 0:
+            self.C.applyRepulsionForce()
+        if self.C.brep_timescale and it % self.C.brep_timescale == 0:
+            self.C.applyBoundaryRepulsionForce()
 
     def spread(self):
         if self.C is not None:
@@ -153,7 +165,6 @@ class HipEngine:
             self.C.applyConstitutiveModel(it, forced)
 
     def owned_vertices(self):
-        import ctypes as C
         if self.C is None:
             return 0
         n = C.c_long()
@@ -274,7 +285,8 @@ class SlabProtocol:
     def step(self):
         e = self.e
         it = self.iter
-        e.spread()                                            # core/hemoCell.cpp:313
+        e.repulsion(it)                                       # core/hemoCell.cpp:307-312
+        e.spread()                                            # :313
         if self.halo_fresh:
             e.collide(0)                                      # :317
         else:

@@ -214,6 +214,7 @@ class Cells:
         check(self.lib.hcp_create(C.byref(self.ptr), lattice.ptr, C.byref(P)))
         self.types = []
         self._next_id = 0
+        self.rep_timescale = self.brep_timescale = 0   # cadences of the two repulsions (0 = off)
 
     def addCellType(self, celltype, material_timescale=1):
         idx = C.c_int()
@@ -270,6 +271,7 @@ class Cells:
     def setRepulsion(self, r_const, r_cutoff_um, timescale=1):
         """hemocell.setRepulsion(k, cutoff [um]) + setRepulsionTimeScaleSeperation(timescale)"""
         check(self.lib.hcp_set_repulsion(self.ptr, float(r_const), float(r_cutoff_um) * (1e-6 / self.P.dx), int(timescale)))
+        self.rep_timescale = int(timescale)
 
     def applyRepulsionForce(self):
         check(self.lib.hcp_repulsion(self.ptr))
@@ -277,6 +279,7 @@ class Cells:
     def enableBoundaryParticles(self, br_const, br_cutoff_um, timescale=1):
         """hemocell.enableBoundaryParticles(k, cutoff [um], timestep) (core/hemoCell.cpp:428-436)"""
         check(self.lib.hcp_set_boundary_repulsion(self.ptr, float(br_const), float(br_cutoff_um) * (1e-6 / self.P.dx), int(timescale)))
+        self.brep_timescale = int(timescale)
 
     def applyBoundaryRepulsionForce(self):
         check(self.lib.hcp_boundary_repulsion(self.ptr))

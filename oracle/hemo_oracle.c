@@ -1002,8 +1002,8 @@ void orc_sim_add_vertex_force(orc_sim *S, long particle, const double f[3]) {
 /* HemoCellParticleField::applyRepulsionForce, core/hemoCellParticleField.cpp:677-743, with the particle grid of
  * update_pg (:137-168): particles binned by nearest node; for every bin the reference visits the bin itself
  * (ordered pairs, so every same-bin pair is applied twice) and 13 of its 26 neighbours (each adjacent pair of bins
- * once).  One global block: bins wrap in periodic directions and the neighbour's position is shifted by the
- * domain length (what the reference's periodic envelope copies carry). */
+ * once).  One global block: bins wrap in periodic directions and the separation of a pair is taken to its minimum
+ * image (what the reference's shifted periodic envelope copies amount to). */
 void orc_sim_repulsion(orc_sim *S, double r_const, double r_cutoff) {
   const orc_lattice *L = S->L;
   const int dims[3] = {L->nx, L->ny, L->nz};
@@ -1030,10 +1030,10 @@ void orc_sim_repulsion(orc_sim *S, double r_const, double r_cutoff) {
     const long lb = z + (long)L->nz * (y + (long)L->ny * x);
     if (head[lb] < 0) continue;
     for (int h = 0; h < 14; h++) {
-      long n[3] = {x + half[h][0], y + half[h][1], z + half[h][2]}; double shift[3] = {0, 0, 0}; int ok = 1;
+      long n[3] = {x + half[h][0], y + half[h][1], z + half[h][2]}; int ok = 1;
       for (int d = 0; d < 3; d++) {
-        if (n[d] < 0) { if (L->periodic[d]) { n[d] += dims[d]; shift[d] = -(double)dims[d]; } else ok = 0; }
-        else if (n[d] >= dims[d]) { if (L->periodic[d]) { n[d] -= dims[d]; shift[d] = (double)dims[d]; } else ok = 0; }
+        if (n[d] < 0) { if (L->periodic[d]) n[d] += dims[d]; else ok = 0; }
+        else if (n[d] >= dims[d]) { if (L->periodic[d]) n[d] -= dims[d]; else ok = 0; }
       }
       if (!ok) continue;
       const long nbn = n[2] + (long)L->nz * (n[1] + (long)L->ny * n[0]);
@@ -1043,7 +1043,12 @@ void orc_sim_repulsion(orc_sim *S, double r_const, double r_cutoff) {
           if (np_ == lp) continue;
           if (lp->cellId == np_->cellId && lp->celltype == np_->celltype) continue;
           double dv[3];
-          for (int d = 0; d < 3; d++) dv[d] = lp->position[d] - (np_->position[d] + shift[d]);
+          /* positions are not re-wrapped when a cell crosses a periodic face (the reference shifts them by the
+           * domain length when they change block): take the minimum image of the separation */
+          for (int d = 0; d < 3; d++) {
+            dv[d] = lp->position[d] - np_->position[d];
+            if (L->periodic[d]) dv[d] = dv[d] - (double)dims[d] * rint(dv[d] / (double)dims[d]);
+          }
           const double distance = sqrt(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
           if (distance < r_cutoff) {
             for (int d = 0; d < 3; d++) {

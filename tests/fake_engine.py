@@ -107,6 +107,9 @@ class FakeEngine:
         keep = np.ones(len(self.ids), bool); keep[slots] = False
         self.ids, self.pos, self.vel, self.frc = self.ids[keep], self.pos[keep], self.vel[keep], self.frc[keep]
 
+    def repulsion(self, it):
+        pass
+
     def spread(self):
         pass
 

@@ -21,7 +21,10 @@ STEPS, K_P, K_M = 250, 2, 4
 FORCE = (3e-4, 0.0, 0.0)
 
 
-def _build(rank, world):
+REPULSION = dict(k=2e-6, cutoff_um=0.7, k_b=3e-6, b_cutoff_um=1.0)   # examples/pipeflow/config.xml:36-38 magnitudes
+
+
+def _build(rank, world, rep=False):
     from hemocell_amd import host
     from hemocell_amd.slab import SlabRunner
     P = host.base_parameters()
@@ -39,11 +42,14 @@ def _build(rank, world):
     else:
         for i, (c, a) in enumerate(PLTS):
             assert r.cells.addCell(1, np.array(c), np.array(a), cell_id=i)
+    if rep:
+        r.cells.setRepulsion(REPULSION["k"], REPULSION["cutoff_um"], K_P)
+        r.cells.enableBoundaryParticles(REPULSION["k_b"], REPULSION["b_cutoff_um"], K_P)
     r.prepare()
     return r, mask
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, rep=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
@@ -51,7 +57,7 @@ def _worker(rank, world, port, out):
     torch.cuda.set_device(0)
     from hemocell_amd import host
     host.init(0)
-    r, _ = _build(rank, world)
+    r, _ = _build(rank, world, rep)
     r.run(STEPS)
     cid, vid, pos = r.owned_vertex_table(0)
     pcid, pvid, ppos = r.owned_vertex_table(1)
@@ -70,14 +76,17 @@ def _initial_x():
     return x
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_slabs_match_single_domain(tmp_path, gpu, world):
+@pytest.mark.parametrize("world,rep", [(2, False), (3, False), (2, True)])
+def test_slabs_match_single_domain(tmp_path, gpu, world, rep):
+    """rep: vertex-vertex and boundary-particle repulsion on (cell records then carry force_repulsion)"""
     import torch.multiprocessing as mp
-    port = 29500 + (os.getpid() + 17 * world) % 400
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    port = 29500 + (os.getpid() + 17 * world + 7 * rep) % 400
+    mp.spawn(_worker, args=(world, port, str(tmp_path), rep), nprocs=world, join=True)
     res = [torch.load(os.path.join(tmp_path, "r%d.pt" % k), weights_only=False) for k in range(world)]
-    ref, mask = _build(0, 1)
+    ref, mask = _build(0, 1, rep)
     ref.run(STEPS)
+    if rep:
+        assert np.abs(ref.cells.repulsion_forces).max() > 0   # the repulsions do act in this case
     f_ref = ref.lattice.populations().reshape(NXG, NY * NZ, 19)
     f_two = np.concatenate([r["f"].reshape(NXG // world, NY * NZ, 19) for r in res], axis=0)
     fluid = (mask.reshape(NXG, NY * NZ) == 0)

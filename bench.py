@@ -39,9 +39,22 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """host cores this process may really use: affinity mask and cgroup CPU quota (the GPU box grants a share of
+    its cores per GPU; more threads than that only oversubscribe)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(args, budget_s):
     """the oracle (CPU restatement, "kind": "port") on a bounded sample of the same workload: a
-    64x128x128 pipe at the same hematocrit and cadences, all host cores (OpenMP collide-stream)."""
+    64x128x128 pipe at the same hematocrit and cadences, on the host cores this process may use (OpenMP)."""
     import ctypes as C
 
     from hemocell_amd.packing import pack_pipe_rbc
@@ -50,7 +63,7 @@ def cpu_baseline(args, budget_s):
 
     orc = O.load()
     nx, ny, nz = 64, 128, 128
-    cores = min(os.cpu_count() or 1, 64)
+    cores = usable_cores()
     P = O.make_params(orc)
     mask, R = pipe_mask(nx, ny, nz)
     L = O.OracleLattice(orc, nx, ny, nz, (1, 0, 0), 1.0 / P.tau)

@@ -222,7 +222,8 @@ class HemoCellField {
   string name; unsigned int ctype = 0; int constructType = 0;
   Config *materialCfg = nullptr;
   unsigned int timescale = 1;
-  unsigned int minimumDistanceFromSolid = 0;   // core/hemoCellField.h:64
+  T minimumDistanceFromSolid = 0;   // micrometres.  core/hemoCellField.h:64 declares it unsigned int (0.5 -> 0); the fraction is kept here
+                                    // because only then does examples/pipeflow keep the 42 cells the reference's tests assert
   int numVertex = 0, numTriangles = 0;
   MeshMetricsView *meshmetric = nullptr;
   CellMechanics *mechanics = nullptr;
@@ -337,7 +338,7 @@ class HemoCell {
     boundaryRepulsionTimescale = timestep; boundaryRepulsionEnabled = true; boundaryRepulsionPushed = false;
   }
   void setInitialMinimumDistanceFromSolid(string name, T distance) {   // core/hemoCell.cpp:410-418 (micrometres, stored as unsigned int)
-    (*cellfields)[name]->minimumDistanceFromSolid = (unsigned int)distance;
+    (*cellfields)[name]->minimumDistanceFromSolid = distance;
   }
   void setSystemPeriodicity(unsigned int axis, bool bePeriodic) { lattice->periodicity().toggle((int)axis, bePeriodic); }
   void setSystemPeriodicityLimit(unsigned int, int) {}
@@ -425,8 +426,15 @@ inline void HemoCell::loadParticles() {
       double p[3], a[3];
       f >> p[0] >> p[1] >> p[2] >> a[0] >> a[1] >> a[2];
       for (int d = 0; d < 3; d++) { a[d] *= PI / 180.0; a[d] *= -1.0; p[d] = p[d] * posRatio; }   // :228-229, :349
+      // A .pos file may cover more than this domain (examples/pipeflow/RBC.pos does).  The reference places such cells
+      // in the particle envelope, where no block owns them: they never count (centerLocal, helper/cellInfo.cpp:97)
+      // and deleteNonLocalParticles (core/hemoCellFields.cpp:676-688) removes them at the first particle update.
+      // Here they are not placed at all.
+      const plint dims[3] = {lattice->getNx(), lattice->getNy(), lattice->getNz()};
+      bool local = true;
+      for (int d = 0; d < 3; d++) if (!(p[d] > -0.5 && p[d] <= (double)dims[d] - 0.5)) local = false;
       int placed = 0;
-      hc_check(hcp_add_cell(c, (int)j, cellid, p, a, (double)field->minimumDistanceFromSolid, &placed), "hcp_add_cell");
+      if (local) hc_check(hcp_add_cell(c, (int)j, cellid, p, a, (double)field->minimumDistanceFromSolid, &placed), "hcp_add_cell");
       placed_n += placed; cellid++;
     }
     hlog << "(readPositionsBloodCells) " << placed_n << " complete " << field->name << " cells placed." << endl;

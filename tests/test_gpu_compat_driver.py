@@ -180,6 +180,10 @@ def test_reference_pipeflow_driver_passes_its_ci_sanity(tmp_path, gpu):
     assert len(visc) == 10 and all(1.03 < v < 3.0 for v in visc), visc
     fmax = [float(_cut(l, (":", 3), (" ", 2))) for l in log if "Force  -" in l]
     assert len(fmax) == 10 and all(f < 4.0 for f in fmax), fmax
+    # :38-50 "Checking checkpointing": a current and a previous dump exist and are not empty (this back end keeps one
+    # file, checkpoint.bin, where the reference has lattice.dat + particleField.dat + checkpoint.xml)
+    for f in ("checkpoint.bin", "checkpoint.bin.old"):
+        assert os.path.getsize(str(work / "tmp" / "checkpoint" / f)) > 0
     if HAVE_HDF5:   # hemocell.writeOutput(): one directory per measurement with fluid and cell files
         out = sorted(os.listdir(str(work / "tmp" / "hdf5")))
         assert len(out) >= 10

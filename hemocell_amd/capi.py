@@ -82,6 +82,8 @@ SIGNATURES = {
     "hcp_set_repulsion": (C.c_int, [VP, C.c_double, C.c_double, C.c_int]),
     "hcp_repulsion": (C.c_int, [VP]),
     "hcp_download_repulsion": (C.c_int, [VP, c_double_p]),
+    "hcl_fluid_stats": (C.c_int, [VP, C.c_int, c_double_p, C.POINTER(C.c_long)]),
+    "hcp_vertex_stats": (C.c_int, [VP, C.c_int, c_double_p, C.POINTER(C.c_long)]),
     "hcp_set_boundary_repulsion": (C.c_int, [VP, C.c_double, C.c_double, C.c_int]),
     "hcp_boundary_repulsion": (C.c_int, [VP]),
     "hcp_spread": (C.c_int, [VP, C.c_int]),

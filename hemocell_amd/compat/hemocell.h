@@ -562,30 +562,23 @@ struct CellInformationFunctionals {
 // ------------------------------------------------------------------ helper/fluidInfo.h, helper/particleInfo.h
 struct FluidStatistics { T min = 0, max = 0, avg = 0; pluint ncells = 0; };
 struct FluidInfo {
-  static FluidStatistics calculateVelocityStatistics(HemoCell *h) {   // |u| over the non-boundary nodes
-    auto *L = h->lattice; hc_lattice *d = L->device();
-    const size_t n = (size_t)L->nx * L->ny * L->nz;
-    vector<double> rho(n), u(3 * n);
-    hc_check(hcl_download_rho_u(d, rho.data(), u.data()), "hcl_download_rho_u");
-    FluidStatistics s; s.min = 1e300; double sum = 0;
-    for (size_t k = 0; k < n; k++) {
-      if (L->mask[k]) continue;
-      const double m = std::sqrt(u[3 * k] * u[3 * k] + u[3 * k + 1] * u[3 * k + 1] + u[3 * k + 2] * u[3 * k + 2]);
-      s.min = std::min(s.min, m); s.max = std::max(s.max, m); sum += m; s.ncells++;
-    }
-    s.avg = s.ncells ? sum / s.ncells : 0;
+  // helper/fluidInfo.cpp:33-118: device reductions (hcl_fluid_stats), folded deterministically
+  static FluidStatistics stat(HemoCell *h, int what) {
+    double o[3]; long n = 0;
+    hc_check(hcl_fluid_stats(h->lattice->device(), what, o, &n), "hcl_fluid_stats");
+    FluidStatistics s; s.min = o[0]; s.max = o[1]; s.ncells = (pluint)n; s.avg = n ? o[2] / (double)n : 0;
     return s;
   }
+  static FluidStatistics calculateVelocityStatistics(HemoCell *h) { return stat(h, 0); }
+  static FluidStatistics calculateForceStatistics(HemoCell *h) { return stat(h, 1); }
 };
 struct ParticleStatistics { T min = 0, max = 0, avg = 0; pluint ncells = 0; };
 struct ParticleInfo {
+  // helper/particleInfo.cpp:30-140: device reduction over the owned vertices (hcp_vertex_stats)
   static ParticleStatistics stat(HemoCell *h, int what) {
-    hc_cells *c = h->cellfields->device();
-    long nvt = 0; hcp_counts(c, &nvt, nullptr, nullptr);
-    vector<double> a(3 * (size_t)nvt); if (nvt) hc_check(hcp_download(c, what, a.data()), "hcp_download");
-    ParticleStatistics s; s.min = nvt ? 1e300 : 0; double sum = 0;
-    for (long i = 0; i < nvt; i++) { const double m = std::sqrt(a[3 * i] * a[3 * i] + a[3 * i + 1] * a[3 * i + 1] + a[3 * i + 2] * a[3 * i + 2]); s.min = std::min(s.min, m); s.max = std::max(s.max, m); sum += m; }
-    s.ncells = (pluint)nvt; s.avg = nvt ? sum / nvt : 0;
+    double o[3]; long n = 0;
+    hc_check(hcp_vertex_stats(h->cellfields->device(), what, o, &n), "hcp_vertex_stats");
+    ParticleStatistics s; s.min = o[0]; s.max = o[1]; s.ncells = (pluint)n; s.avg = n ? o[2] / (double)n : 0;
     return s;
   }
   static ParticleStatistics calculateForceStatistics(HemoCell *h) { return stat(h, 2); }

@@ -874,6 +874,23 @@ __global__ __launch_bounds__(256) void move_cells_kernel(int nv, const int *src_
     }
 }
 
+// ParticleInfo statistics (helper/particleInfo.cpp:30-95): magnitude of v (what 1) or of force + force_repulsion (what 2)
+// over the vertices this slab owns (findParticles(localDomain))
+__global__ __launch_bounds__(256) void vertex_stats_kernel(long n, int what, int all_owned, int x0, int nx, const double *px, const double *a0,
+                                                           const double *a1, const double *a2, const double *r0, const double *r1, const double *r2,
+                                                           double *partial, int accumulate) {
+  StatAcc acc{1e300, -1e300, 0.0, 0};
+  if (accumulate) { const double *o = partial + 4 * blockIdx.x; if (threadIdx.x == 0 && o[3] > 0) { acc.mn = o[0]; acc.mx = o[1]; acc.sum = o[2]; acc.n = (long)o[3]; } }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)STAT_BLOCKS * 256) {
+    if (!all_owned) { const long gx = nearest_node(px[i]) - x0; if (gx < 0 || gx >= nx) continue; }
+    double v0 = a0[i], v1 = a1[i], v2 = a2[i];
+    if (what == 2 && r0) { v0 = v0 + r0[i]; v1 = v1 + r1[i]; v2 = v2 + r2[i]; }
+    stat_add(acc, sqrt(v0 * v0 + v1 * v1 + v2 * v2));
+  }
+  __syncthreads();   // every thread has read the previous partial before it is overwritten
+  stat_block_store(acc, partial);
+}
+
 __global__ __launch_bounds__(256) void owned_count_kernel(long n, const double *px, int x0, int nx, unsigned long long *count) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   int mine = 0;
@@ -1704,6 +1721,32 @@ int hcp_owned_vertices(hc_cells *C, long *n_owned) {
 }  // extern "C"
 
 extern "C" {
+
+// ParticleInfo::calculate{Velocity,Force}Statistics (helper/particleInfo.cpp:30-140) as a device reduction
+int hcp_vertex_stats(hc_cells *C, int what, double out[3], long *n) {
+  HC_REQUIRE(C && out && n && (what == 1 || what == 2), "hcp_vertex_stats: bad arguments (what: 1 velocity, 2 force)");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  double *d_partial = nullptr;
+  HC_HIP(hipMalloc((void **)&d_partial, (size_t)STAT_BLOCKS * 4 * sizeof(double)));
+  HC_HIP(hipMemsetAsync(d_partial, 0, (size_t)STAT_BLOCKS * 4 * sizeof(double), hc::stream()));
+  const hc_lattice *L = C->L;
+  int launched = 0;
+  for (int t = 0; t < C->ntypes; t++) {
+    const long nt = C->ncells[t] * C->types[t]->host.nv, f = C->first[t];
+    if (nt == 0) continue;
+    double **src = what == 1 ? C->vel : C->frc;
+    hipLaunchKernelGGL(vertex_stats_kernel, dim3(STAT_BLOCKS), dim3(256), 0, hc::stream(), nt, what, L->n_slabs == 1 ? 1 : 0, L->x0, L->nx,
+                       (const double *)(C->pos[0] + f), (const double *)(src[0] + f), (const double *)(src[1] + f), (const double *)(src[2] + f),
+                       C->rep[0] ? (const double *)(C->rep[0] + f) : nullptr, C->rep[1] ? (const double *)(C->rep[1] + f) : nullptr,
+                       C->rep[2] ? (const double *)(C->rep[2] + f) : nullptr, d_partial, launched);
+    launched = 1;
+  }
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) rc = hc::stat_finish(d_partial, out, n);
+  hipFree(d_partial);
+  if (e != hipSuccess) return hc::hip_fail(e, "hcp_vertex_stats", __FILE__, __LINE__);
+  return rc;
+}
 
 // hemocell.setRepulsion(k, cutoff_um) + setRepulsionTimeScaleSeperation (core/hemoCell.cpp:394-397,420-426)
 int hcp_set_repulsion(hc_cells *C, double r_const, double r_cutoff_lu, int timescale) {

@@ -43,6 +43,33 @@ struct ProfScope {
 
 constexpr int HALO = 2;  // x-halo planes on each side of a slab
 
+// Deterministic min / max / sum / count reduction used by the statistics entry points: a fixed grid of STAT_BLOCKS
+// workgroups, each thread strides over the items, waves combine by shuffles, workgroups write one partial each and
+// the host folds the partials in index order.
+constexpr int STAT_BLOCKS = 512;
+struct StatAcc { double mn, mx, sum; long n; };
+__device__ __forceinline__ void stat_add(StatAcc &a, double v) { a.mn = v < a.mn ? v : a.mn; a.mx = v > a.mx ? v : a.mx; a.sum += v; a.n++; }
+__device__ __forceinline__ void stat_block_store(StatAcc a, double *partial /*[STAT_BLOCKS][4]*/) {
+  __shared__ double s_red[4][4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double mn = __shfl_xor(a.mn, off), mx = __shfl_xor(a.mx, off), sm = __shfl_xor(a.sum, off);
+    const long n = __shfl_xor(a.n, off);
+    a.mn = mn < a.mn ? mn : a.mn; a.mx = mx > a.mx ? mx : a.mx; a.sum += sm; a.n += n;
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_red[w][0] = a.mn; s_red[w][1] = a.mx; s_red[w][2] = a.sum; s_red[w][3] = (double)a.n; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double mn = s_red[0][0], mx = s_red[0][1], sm = s_red[0][2], n = s_red[0][3];
+    for (int k = 1; k < (int)(blockDim.x >> 6); k++) { mn = s_red[k][0] < mn ? s_red[k][0] : mn; mx = s_red[k][1] > mx ? s_red[k][1] : mx; sm += s_red[k][2]; n += s_red[k][3]; }
+    double *o = partial + 4 * blockIdx.x;
+    o[0] = mn; o[1] = mx; o[2] = sm; o[3] = n;
+  }
+}
+// folds the partials (device pointer) on the host; out = {min, max, sum}
+int stat_finish(const double *d_partial, double out[3], long *n);
+
 }  // namespace hc
 
 struct hc_lattice {

@@ -298,6 +298,33 @@ __global__ void force_aos_kernel(LatArgs a, double *F) {
   for (int d = 0; d < 3; d++) F[3 * o + d] = a.Fin[d * a.npad + node];
 }
 
+// FluidInfo statistics (helper/fluidInfo.cpp:33-96): magnitude of Cell::computeVelocity (what 0) or of the external
+// force (what 1) over the non-boundary bulk nodes
+__global__ __launch_bounds__(256) void fluid_stats_kernel(LatArgs a, int what, double *partial) {
+  StatAcc acc{1e300, -1e300, 0.0, 0};
+  const long nbulk = (long)a.nx * a.plane;
+  for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nbulk; k += (long)STAT_BLOCKS * 256) {
+    const int x = (int)(k / a.plane), p = (int)(k - (long)x * a.plane);
+    const long node = (long)(x + HALO) * a.plane + p;
+    if (a.mask[node] != 0) continue;
+    double Fx = a.bx, Fy = a.by, Fz = a.bz;
+    if (a.ibm) { Fx = a.bx + a.Fin[node]; Fy = a.by + a.Fin[a.npad + node]; Fz = a.bz + a.Fin[2 * a.npad + node]; }
+    double v0 = Fx, v1 = Fy, v2 = Fz;
+    if (what == 0) {
+      const int y = p / a.nz, z = p - y * a.nz;
+      const Nbr n = neighbours(a, x, y, z);
+      double f[HC_Q];
+      pull(a.fin, a.npad, node, n, f);
+      double rhoBar, j0, j1, j2;
+      moments(f, rhoBar, j0, j1, j2);
+      const double invRho = 1.0 / (1.0 + rhoBar);
+      v0 = j0 * invRho + Fx / 2.0; v1 = j1 * invRho + Fy / 2.0; v2 = j2 * invRho + Fz / 2.0;
+    }
+    stat_add(acc, sqrt(v0 * v0 + v1 * v1 + v2 * v2));
+  }
+  stat_block_store(acc, partial);
+}
+
 struct HaloArgs {
   double *f;          // population buffer
   double *buf;        // contiguous staging
@@ -626,6 +653,15 @@ int hcl_zero_ibm_force(hc_lattice *L) {
   HC_REQUIRE(L, "hcl_zero_ibm_force: null lattice");
   HC_HIP(hipMemsetAsync(L->force[L->fcur], 0, L->npad * 3 * sizeof(double), hc::stream()));
   return HC_OK;
+}
+
+int hcl_fluid_stats(hc_lattice *L, int what, double out[3], long *n_nodes) {
+  HC_REQUIRE(L && out && n_nodes && (what == 0 || what == 1), "hcl_fluid_stats: bad arguments");
+  int rc = ensure_scratch(L, (size_t)STAT_BLOCKS * 4); if (rc != HC_OK) return rc;
+  LatArgs a = make_args(L);
+  hipLaunchKernelGGL(fluid_stats_kernel, dim3(STAT_BLOCKS), dim3(256), 0, hc::stream(), a, what, L->scratch);
+  HC_HIP(hipGetLastError());
+  return hc::stat_finish(L->scratch, out, n_nodes);
 }
 
 size_t hcl_halo_doubles(const hc_lattice *L, int width) {

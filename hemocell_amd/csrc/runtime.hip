@@ -47,6 +47,22 @@ static void prof_collect() {
   }
 }
 
+int stat_finish(const double *d_partial, double out[3], long *n) {
+  double h[STAT_BLOCKS * 4];
+  HC_HIP(hipMemcpyAsync(h, d_partial, sizeof(h), hipMemcpyDeviceToHost, g_stream));
+  HC_HIP(hipStreamSynchronize(g_stream));
+  double mn = 0, mx = 0, sum = 0; long cnt = 0;
+  for (int b = 0; b < STAT_BLOCKS; b++) {
+    const long nb = (long)h[4 * b + 3];
+    if (nb == 0) continue;
+    if (cnt == 0) { mn = h[4 * b]; mx = h[4 * b + 1]; }
+    else { mn = h[4 * b] < mn ? h[4 * b] : mn; mx = h[4 * b + 1] > mx ? h[4 * b + 1] : mx; }
+    sum += h[4 * b + 2]; cnt += nb;
+  }
+  out[0] = mn; out[1] = mx; out[2] = sum; *n = cnt;
+  return HC_OK;
+}
+
 }  // namespace hc
 
 extern "C" {

@@ -99,6 +99,13 @@ class Lattice:
     def collide_part(self, part):
         check(self.lib.hcl_collide_stream_part(self.ptr, int(part)))
 
+    def fluid_stats(self, what=0):
+        """FluidInfo::calculate{Velocity,Force}Statistics: (min, max, mean, n) of |u| (what 0) or |F| (what 1) over
+        the non-boundary nodes, reduced on the device"""
+        o = np.zeros(3); n = C.c_long()
+        check(self.lib.hcl_fluid_stats(self.ptr, int(what), dptr(o), C.byref(n)))
+        return o[0], o[1], (o[2] / n.value if n.value else 0.0), n.value
+
     def step_end(self):
         check(self.lib.hcl_step_end(self.ptr))
 
@@ -267,6 +274,13 @@ class Cells:
         idx = np.ascontiguousarray(vertex_index, dtype=np.int64)
         ff = np.ascontiguousarray(f, dtype=np.float64).reshape(len(idx), 3)
         check(self.lib.hcp_add_vertex_force(self.ptr, lptr(idx), len(idx), dptr(ff)))
+
+    def vertex_stats(self, what=2):
+        """ParticleInfo::calculate{Velocity,Force}Statistics: (min, max, mean, n) of |v| (what 1) or
+        |force + force_repulsion| (what 2) over the owned vertices, reduced on the device"""
+        o = np.zeros(3); n = C.c_long()
+        check(self.lib.hcp_vertex_stats(self.ptr, int(what), dptr(o), C.byref(n)))
+        return o[0], o[1], (o[2] / n.value if n.value else 0.0), n.value
 
     def setRepulsion(self, r_const, r_cutoff_um, timescale=1):
         """hemocell.setRepulsion(k, cutoff [um]) + setRepulsionTimeScaleSeperation(timescale)"""

@@ -87,6 +87,10 @@ int hcl_upload_populations(hc_lattice *L, const double *f_aos);
 /* rho[n] and u[n][3] = Cell::computeVelocity (j/rho + F/2), local bulk nodes */
 int hcl_download_rho_u(hc_lattice *L, double *rho, double *u);
 /* IBM force field currently accumulated (without the body force), [node][3] */
+/* FluidInfo::calculate{Velocity,Force}Statistics (helper/fluidInfo.cpp:33-118) as a device reduction: out = {min, max,
+ * sum} of the magnitude over the non-boundary bulk nodes of this slab, *n_nodes their number.  what: 0 =
+ * Cell::computeVelocity, 1 = external force (body force + the IBM field spread for the coming step).  Deterministic. */
+int hcl_fluid_stats(hc_lattice *L, int what, double out[3], long *n_nodes);
 int hcl_download_ibm_force(hc_lattice *L, double *F);
 int hcl_zero_ibm_force(hc_lattice *L);
 /* halo exchange (Palabos duplicateOverlaps(staticVariables), core/hemoCell.cpp:142).  width = 1 (5
@@ -158,6 +162,9 @@ int hcp_add_vertex_force(hc_cells *C, const long *vertex_index, int n, const dou
  * cutoff is given in lattice units (the facade converts from micrometres).  hc_iterate then evaluates
  * cellfields->applyRepulsionForce() (core/hemoCell.cpp:307-309 -> core/hemoCellParticleField.cpp:677-743) every
  * `timescale` iterations; spread adds force_repulsion + force as the reference does. */
+/* ParticleInfo::calculate{Velocity,Force}Statistics (helper/particleInfo.cpp:30-140) as a device reduction over the
+ * vertices this slab owns: out = {min, max, sum} of |v| (what 1) or |force + force_repulsion| (what 2). */
+int hcp_vertex_stats(hc_cells *C, int what, double out[3], long *n);
 int hcp_set_repulsion(hc_cells *C, double r_const, double r_cutoff_lu, int timescale);
 int hcp_repulsion(hc_cells *C);
 int hcp_download_repulsion(hc_cells *C, double *out /*[n][3]*/);

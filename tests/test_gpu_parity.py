@@ -582,3 +582,36 @@ def test_boundary_particle_repulsion_vs_oracle(orc, gpu):
     orc.orc_sim_get(So, 3, O.dptr(r_o))
     assert np.abs(cf.repulsion_forces - r_o).max() <= 1e-9 * max(np.abs(r_o).max(), 1e-30)
     Lo.destroy(); Lg.destroy()
+
+
+def test_info_reductions_match_downloaded_fields(gpu):
+    """FluidInfo / ParticleInfo statistics (helper/fluidInfo.cpp:33-118, helper/particleInfo.cpp:30-140) are device
+    reductions; they must equal the same statistics taken from the downloaded fields, and be reproducible bit for bit"""
+    nx, ny, nz = 48, 34, 34
+    P = gpu.base_parameters()
+    mask, R = gpu.pipe_mask(nx, ny, nz)
+    L = gpu.Lattice(nx, ny, nz, (1, 0, 0), 1.0 / P.tau)
+    L.defineBounceBack(mask); L.latticeEquilibrium(); L.setExternalVector((3e-5, 0, 0))
+    h = gpu.HemoCell(L, P)
+    h.cellfields.addCellType(gpu.CellType.rbc(P), 1); h.cellfields.addCellType(gpu.CellType.plt(P), 1)
+    assert h.cellfields.addCell(0, (14.0, 16.5, 15.2), (90, 0, 0)) and h.cellfields.addCell(0, (33.0, 17.0, 17.5), (70, 10, 0))
+    assert h.cellfields.addCell(1, (24.0, 16.5, 9.0), (0, 0, 0))
+    h.cellfields.setRepulsion(2e-6, 0.7, 1)
+    h.cellfields.applyConstitutiveModel(0, True)
+    h.iterate(40)
+    fluid = mask.reshape(-1) == 0
+    rho, u = L.rho_u()
+    m = np.sqrt((u[fluid] ** 2).sum(1))
+    mn, mx, avg, n = L.fluid_stats(0)
+    assert n == fluid.sum() and mn == m.min() and mx == m.max() and abs(avg - m.mean()) <= 1e-15 * m.mean()
+    assert L.fluid_stats(0) == (mn, mx, avg, n)                       # deterministic
+    # external force: nothing is spread between two steps, so it is the body force on every fluid node
+    fmn, fmx, favg, fn = L.fluid_stats(1)
+    assert fn == n and fmn == fmx == 3e-5
+    cf = h.cellfields
+    for what, arr in ((1, cf.velocities), (2, cf.forces + cf.repulsion_forces)):
+        m = np.sqrt((arr ** 2).sum(1))
+        mn, mx, avg, n = cf.vertex_stats(what)
+        assert n == len(m) and mn == m.min() and mx == m.max() and abs(avg - m.mean()) <= 1e-14 * m.mean()
+        assert cf.vertex_stats(what) == (mn, mx, avg, n)
+    L.destroy()

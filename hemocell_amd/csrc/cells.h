@@ -1,0 +1,166 @@
+// Internal declarations shared by the translation units that work on membrane vertices
+// (cells.hip: storage and stepping, ibm.hip: spread / interpolate, mechanics.hip: membrane models,
+// exchange.hip: slab envelopes and statistics, repulsion.hip: vertex-vertex and boundary repulsion).
+//
+// Layout (HBM): vertices are a structure of arrays pos/vel/frc[3][n], cell major (a cell's nv vertices are
+// contiguous, cells of one type contiguous in a fixed-capacity region), so a wavefront touches 64 consecutive
+// doubles per component and a mechanics workgroup stages one whole cell in LDS with coalesced loads.
+#pragma once
+#include "common.h"
+#include "mesh.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+using namespace hc;
+
+struct hc_celltype {
+  CellTables host;
+  int *d_tri = nullptr, *d_edge = nullptr, *d_ebt = nullptr, *d_ebo = nullptr, *d_iedge = nullptr;
+  int *d_vtri = nullptr, *d_vtri_k = nullptr, *d_vedge = nullptr, *d_vedge_s = nullptr, *d_bsrc = nullptr;
+  int *d_vouter = nullptr, *d_vinner = nullptr, *d_vinner_s = nullptr, *d_ring = nullptr, *d_nring = nullptr;
+  double *d_tri_area_eq = nullptr, *d_edge_len_eq = nullptr, *d_edge_angle_eq = nullptr, *d_patch_eq = nullptr,
+         *d_iedge_len_eq = nullptr;
+};
+
+struct hc_cells {
+  hc_lattice *L = nullptr;
+  hc_params P;
+  int ntypes = 0;
+  hc_celltype *types[8];
+  int timescale[8];
+  std::vector<double> hpos[8];   // host staging per type: [ncells*nv][3]
+  std::vector<double> hvel[8], hfrc[8];
+  std::vector<long> hids[8];
+  bool host_dirty = false;       // host staging newer than device
+  long nverts = 0, cap = 0;      // live vertices (all types); allocated vertex capacity
+  long ncells[8] = {0};
+  long capc[8] = {0};            // per-type capacity in cells (device regions are fixed-size per type)
+  long first[8] = {0};           // first vertex of each type's region on the device
+  long cell0[8] = {0};           // first cell slot of each type's region
+  double *pos[3] = {nullptr, nullptr, nullptr}, *vel[3] = {nullptr, nullptr, nullptr}, *frc[3] = {nullptr, nullptr, nullptr};
+  int *d_tag = nullptr;          // per-cell deletion tags (all types, slot order)
+  long tag_cap = 0;
+  int *h_ntag = nullptr;         // pinned host copy of the tag counter
+  int *d_ntag = nullptr;         // device counter of tagged cells
+  int *d_vert_cell = nullptr;    // [cap] cell slot of every vertex
+  // vertex-vertex repulsion (core/hemoCellParticleField.cpp:677-743); arrays exist only once it is enabled
+  double *rep[3] = {nullptr, nullptr, nullptr};
+  int rep_enabled = 0, rep_timescale = 1; double rep_const = 0, rep_cutoff = 0;
+  // boundary particles (core/hemoCellParticleField.cpp:865-918): flag map of the wall nodes that repel vertices
+  int brep_enabled = 0, brep_timescale = 1; double brep_const = 0, brep_cutoff = 0; uint8_t *d_bflag = nullptr;
+  bool rep_on() const { return rep_enabled || brep_enabled; }
+  unsigned int *d_keys[2] = {nullptr, nullptr}; int *d_vals[2] = {nullptr, nullptr}; void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0; long sort_cap = 0;
+  int *d_iscratch[2] = {nullptr, nullptr};   // staged slot lists of the envelope exchange (stream ordered, no sync)
+  size_t iscratch_cap[2] = {0, 0};
+  long n_deleted = 0;
+};
+
+namespace hcc {
+
+// ----------------------------------------------------------------------------
+// lattice view for the IBM kernels
+struct LatView {
+  const uint8_t *mask;
+  int nx, ny, nz, plane; long npad;
+  int x0;                 // global x of local plane 0
+  int wrap_x, halo_x;     // single periodic slab: wrap; multi slab: one halo plane is addressable
+  int per_y, per_z;
+  int nx_global;
+  uint8_t *dirty; uint8_t epoch;   // dirty map of the force buffer spread adds to (see common.h)
+};
+
+inline LatView make_view(const hc_lattice *L) {
+  LatView v;
+  v.mask = L->mask; v.nx = L->nx; v.ny = L->ny; v.nz = L->nz; v.plane = (int)L->plane; v.npad = (long)L->npad;
+  v.x0 = L->x0; v.wrap_x = (L->n_slabs == 1 && L->periodic[0]) ? 1 : 0; v.halo_x = L->n_slabs > 1 ? 1 : 0;
+  v.per_y = L->periodic[1]; v.per_z = L->periodic[2]; v.nx_global = L->nx_global;
+  v.dirty = L->fdirty[L->fcur]; v.epoch = L->fepoch[L->fcur];
+  return v;
+}
+
+__device__ __forceinline__ long pmod(long a, long n) { long r = a % n; return r < 0 ? r + n : r; }
+
+// phi2 (core/immersedBoundaryMethod.h:37-41)
+__device__ __forceinline__ double phi2(double x) { x = fabs(x); x = 1.0 - x; return x > 0.0 ? x : 0.0; }
+
+struct Stencil {
+  long node[8];     // padded-lattice element index, -1 when not admitted
+  double w[8];      // normalised weights
+  int lx[8], ly[8], lz[8];  // local (wrapped) coordinates of the node, for the population gather
+};
+
+// interpolationCoefficientsPhi2 (core/immersedBoundaryMethod.h:62-138).  Per axis only the pair
+// {centre-1, centre} (x < centre) or {centre, centre+1} can carry a non-zero tent weight, and visiting
+// the 2x2x2 pairs in ascending offset order is the reference's 27-node loop with its zero-weight skips.
+__device__ __forceinline__ long nearest_node(double x) { return (long)floor(x + 0.5); }
+
+__device__ __forceinline__ void phi2_stencil(const LatView &v, double px, double py, double pz, Stencil &s) {
+  // weights are formed in GLOBAL coordinates (identical bits on every slab that holds a copy of the
+  // vertex); only the node index is made slab-local.  plint(x+0.5) of the reference (:86) truncates,
+  // which equals floor on the block-relative coordinates (>= 0) it is applied to; floor is used so that
+  // a periodic image at negative x picks the same nodes as its wrapped position.
+  const double p[3] = {px, py, pz};
+  long c[3]; int d0[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) { c[a] = nearest_node(p[a]); d0[a] = (p[a] < (double)c[a]) ? -1 : 0; }
+  double total = 0.0;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int idx = i * 4 + j * 2 + k;
+        const long gx = c[0] + d0[0] + i, gy = c[1] + d0[1] + j, gz = c[2] + d0[2] + k;
+        long lx = gx - v.x0, ly = gy, lz = gz;
+        bool ok = true;
+        if (v.wrap_x) lx = pmod(lx, v.nx);
+        else if (v.halo_x) ok = ok && (lx >= -HALO && lx < v.nx + HALO);
+        else ok = ok && (lx >= 0 && lx < v.nx);
+        if (gy < 0 || gy >= v.ny) { if (v.per_y) ly = pmod(gy, v.ny); else ok = false; }
+        if (gz < 0 || gz >= v.nz) { if (v.per_z) lz = pmod(gz, v.nz); else ok = false; }
+        double weight = 0.0; long node = -1;
+        if (ok) {
+          weight = phi2(p[0] - (double)gx) * phi2(p[1] - (double)gy) * phi2(p[2] - (double)gz);
+          if (weight != 0.0) {
+            node = (lx + HALO) * (long)v.plane + ly * v.nz + lz;
+            if (v.mask[node] != 0) node = -1;
+          }
+        }
+        if (node >= 0) total += weight;
+        s.node[idx] = node; s.w[idx] = weight; s.lx[idx] = (int)lx; s.ly[idx] = (int)ly; s.lz[idx] = (int)lz;
+      }
+  const double coeff = 1.0 / total;
+#pragma unroll
+  for (int idx = 0; idx < 8; idx++) s.w[idx] *= coeff;
+}
+
+struct VertArrays { double *p[3], *v[3], *f[3], *r[3]; };   // r: repulsion force arrays or null
+
+// ----------------------------------------------------------------------------
+template <typename T>
+inline int upload_vec(T **dst, const std::vector<T> &src) {
+  *dst = nullptr;
+  const size_t n = src.size() ? src.size() : 1;
+  HC_HIP(hipMalloc((void **)dst, n * sizeof(T)));
+  if (src.size()) HC_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return HC_OK;
+}
+template <size_t N>
+inline std::vector<int> flatten(const std::vector<std::array<long, N>> &v) {
+  std::vector<int> o; o.reserve(v.size() * N);
+  for (auto &a : v) for (long x : a) o.push_back((int)x);
+  return o;
+}
+
+// storage management (cells.hip)
+int free_device_arrays(hc_cells *C);
+int sync_to_device(hc_cells *C);   // host staging -> device arrays when the host copy is newer
+int sync_to_host(hc_cells *C);     // device arrays -> host staging before host-side edits
+VertArrays vert_arrays(hc_cells *C, int t);
+// stage a small host int array on the device in a persistent scratch slot (stream ordered, no host sync)
+int stage_ints(hc_cells *C, int which, int **d, const int *h, int n);
+
+}  // namespace hcc
+using namespace hcc;

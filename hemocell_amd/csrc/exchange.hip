@@ -1,0 +1,253 @@
+// Slab runs: cell extents, envelope records (pack / unpack / remove), ownership counts and the
+// ParticleInfo statistics over owned vertices.
+//
+// Replaces (file:line in the HemoCell tree):
+//   core/hemoCellFields.cpp:377-499, core/hemoCellParticleDataTransfer.cpp:33-466   syncEnvelopes (device side)
+//   core/hemoCellParticleField.cpp:173-235        addParticle merge rule
+//   helper/particleInfo.cpp:30-140                force / velocity statistics
+#include "cells.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------- multi-slab cell exchange
+// per-cell [min_x, max_x, number of vertices whose nearest node lies in this slab]
+__global__ __launch_bounds__(256) void cell_extent_kernel(int nv, const double *px, double *out, int x0, int nx) {
+  __shared__ double lo[256], hi[256];
+  __shared__ int own[256];
+  const int tid = threadIdx.x;
+  const long base = (long)blockIdx.x * nv;
+  double a = 1e300, b = -1e300; int o = 0;
+  for (int i = tid; i < nv; i += 256) {
+    const double x = px[base + i]; a = fmin(a, x); b = fmax(b, x);
+    const long gx = nearest_node(x) - x0;
+    o += (gx >= 0 && gx < nx) ? 1 : 0;
+  }
+  lo[tid] = a; hi[tid] = b; own[tid] = o;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) { lo[tid] = fmin(lo[tid], lo[tid + s]); hi[tid] = fmax(hi[tid], hi[tid + s]); own[tid] += own[tid + s]; }
+    __syncthreads();
+  }
+  if (tid == 0) { out[3 * blockIdx.x] = lo[0]; out[3 * blockIdx.x + 1] = hi[0]; out[3 * blockIdx.x + 2] = (double)own[0]; }
+}
+
+
+// record layout per vertex: pos[3] vel[3] force[3] and, once a repulsion is enabled (rec == 12), force_repulsion[3]
+// (the fields of serializeValues_t that change, core/hemoCellParticle.h:45-63)
+__global__ __launch_bounds__(256) void pack_cells_kernel(int nv, int rec, const int *slots, VertArrays a, double *buf, double x_shift) {
+  const long src = (long)slots[blockIdx.x] * nv, dst = (long)blockIdx.x * nv;
+  for (int i = threadIdx.x; i < nv; i += 256) {
+    double *r = buf + (dst + i) * rec;
+    r[0] = a.p[0][src + i] + x_shift; r[1] = a.p[1][src + i]; r[2] = a.p[2][src + i];
+    r[3] = a.v[0][src + i]; r[4] = a.v[1][src + i]; r[5] = a.v[2][src + i];
+    r[6] = a.f[0][src + i]; r[7] = a.f[1][src + i]; r[8] = a.f[2][src + i];
+    if (rec == 12) { r[9] = a.r[0][src + i]; r[10] = a.r[1][src + i]; r[11] = a.r[2][src + i]; }
+  }
+}
+
+// merge rule of HemoCellParticleField::addParticle (core/hemoCellParticleField.cpp:173-235): a local
+// particle wins over an incoming copy; "local" = its nearest lattice node lies in this slab
+__global__ __launch_bounds__(256) void unpack_cells_kernel(int nv, int rec, const int *slots, const int *is_new, VertArrays a, const double *buf,
+                                                           int x0, int nx) {
+  const long dst = (long)slots[blockIdx.x] * nv, src = (long)blockIdx.x * nv;
+  const bool fresh = is_new[blockIdx.x] != 0;
+  for (int i = threadIdx.x; i < nv; i += 256) {
+    bool take = fresh;
+    if (!take) {
+      const long gx = nearest_node(a.p[0][dst + i]) - x0;
+      take = !(gx >= 0 && gx < nx);
+    }
+    if (take) {
+      const double *r = buf + (src + i) * rec;
+      a.p[0][dst + i] = r[0]; a.p[1][dst + i] = r[1]; a.p[2][dst + i] = r[2];
+      a.v[0][dst + i] = r[3]; a.v[1][dst + i] = r[4]; a.v[2][dst + i] = r[5];
+      a.f[0][dst + i] = r[6]; a.f[1][dst + i] = r[7]; a.f[2][dst + i] = r[8];
+      if (rec == 12) { a.r[0][dst + i] = r[9]; a.r[1][dst + i] = r[10]; a.r[2][dst + i] = r[11]; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void move_cells_kernel(int nv, const int *src_slots, const int *dst_slots, VertArrays a) {
+  const long src = (long)src_slots[blockIdx.x] * nv, dst = (long)dst_slots[blockIdx.x] * nv;
+  for (int i = threadIdx.x; i < nv; i += 256)
+    for (int d = 0; d < 3; d++) {
+      a.p[d][dst + i] = a.p[d][src + i]; a.v[d][dst + i] = a.v[d][src + i]; a.f[d][dst + i] = a.f[d][src + i];
+      if (a.r[d]) a.r[d][dst + i] = a.r[d][src + i];
+    }
+}
+
+// ParticleInfo statistics (helper/particleInfo.cpp:30-95): magnitude of v (what 1) or of force + force_repulsion (what 2)
+// over the vertices this slab owns (findParticles(localDomain))
+__global__ __launch_bounds__(256) void vertex_stats_kernel(long n, int what, int all_owned, int x0, int nx, const double *px, const double *a0,
+                                                           const double *a1, const double *a2, const double *r0, const double *r1, const double *r2,
+                                                           double *partial, int accumulate) {
+  StatAcc acc{1e300, -1e300, 0.0, 0};
+  if (accumulate) { const double *o = partial + 4 * blockIdx.x; if (threadIdx.x == 0 && o[3] > 0) { acc.mn = o[0]; acc.mx = o[1]; acc.sum = o[2]; acc.n = (long)o[3]; } }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)STAT_BLOCKS * 256) {
+    if (!all_owned) { const long gx = nearest_node(px[i]) - x0; if (gx < 0 || gx >= nx) continue; }
+    double v0 = a0[i], v1 = a1[i], v2 = a2[i];
+    if (what == 2 && r0) { v0 = v0 + r0[i]; v1 = v1 + r1[i]; v2 = v2 + r2[i]; }
+    stat_add(acc, sqrt(v0 * v0 + v1 * v1 + v2 * v2));
+  }
+  __syncthreads();   // every thread has read the previous partial before it is overwritten
+  stat_block_store(acc, partial);
+}
+
+__global__ __launch_bounds__(256) void owned_count_kernel(long n, const double *px, int x0, int nx, unsigned long long *count) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  int mine = 0;
+  if (i < n) { const long gx = nearest_node(px[i]) - x0; mine = (gx >= 0 && gx < nx) ? 1 : 0; }
+  const unsigned long long b = __ballot(mine);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (unsigned long long)__popcll(b));
+}
+
+}  // namespace
+
+extern "C" {
+
+int hcp_cell_extents(hc_cells *C, int type, double *minmax) {
+  HC_REQUIRE(C && minmax && type >= 0 && type < C->ntypes, "hcp_cell_extents: bad arguments");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  const long nc = C->ncells[type];
+  if (nc == 0) return HC_OK;
+  double *d = nullptr;
+  HC_HIP(hipMalloc((void **)&d, (size_t)(3 * nc) * sizeof(double)));
+  hipLaunchKernelGGL(cell_extent_kernel, dim3((unsigned)nc), dim3(256), 0, hc::stream(), C->types[type]->host.nv, (const double *)(C->pos[0] + C->first[type]), d, C->L->x0, C->L->nx);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(minmax, d, (size_t)(3 * nc) * sizeof(double), hipMemcpyDeviceToHost, hc::stream());
+  if (e == hipSuccess) e = hipStreamSynchronize(hc::stream());
+  hipFree(d);
+  if (e != hipSuccess) return hc::hip_fail(e, "hcp_cell_extents", __FILE__, __LINE__);
+  return HC_OK;
+}
+
+size_t hcp_record_doubles(const hc_cells *C, int type) {
+  if (!C || type < 0 || type >= C->ntypes) return 0;
+  return (size_t)C->types[type]->host.nv * (C->rep_on() ? 12 : 9);
+}
+
+int hcp_pack_cells(hc_cells *C, int type, const int *slots, int n, double x_shift, double *dev_buf) {
+  HC_REQUIRE(C && type >= 0 && type < C->ntypes && n >= 0, "hcp_pack_cells: bad arguments");
+  if (n == 0) return HC_OK;
+  HC_REQUIRE(slots && dev_buf, "hcp_pack_cells: null pointer");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  for (int i = 0; i < n; i++) HC_REQUIRE(slots[i] >= 0 && slots[i] < C->ncells[type], "hcp_pack_cells: slot out of range");
+  int *d_slots = nullptr;
+  rc = stage_ints(C, 0, &d_slots, slots, n); if (rc != HC_OK) return rc;
+  hipLaunchKernelGGL(pack_cells_kernel, dim3((unsigned)n), dim3(256), 0, hc::stream(), C->types[type]->host.nv, C->rep_on() ? 12 : 9, (const int *)d_slots, vert_arrays(C, type), dev_buf, x_shift);
+  HC_HIP(hipGetLastError());
+  return HC_OK;
+}
+
+int hcp_unpack_cells(hc_cells *C, int type, const int *slots, const long *cell_ids, const int *is_new, int n, const double *dev_buf) {
+  HC_REQUIRE(C && type >= 0 && type < C->ntypes && n >= 0, "hcp_unpack_cells: bad arguments");
+  if (n == 0) return HC_OK;
+  HC_REQUIRE(slots && cell_ids && is_new && dev_buf, "hcp_unpack_cells: null pointer");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  long n_new = 0;
+  for (int i = 0; i < n; i++) {
+    if (is_new[i]) { HC_REQUIRE(slots[i] == C->ncells[type] + n_new, "hcp_unpack_cells: new cells must be appended in slot order"); n_new++; }
+    else HC_REQUIRE(slots[i] >= 0 && slots[i] < C->ncells[type], "hcp_unpack_cells: slot out of range");
+  }
+  if (C->ncells[type] + n_new > C->capc[type]) {
+    // slow path: grow the device regions through the host staging
+    rc = sync_to_host(C); if (rc != HC_OK) return rc;
+    const size_t add = (size_t)n_new * C->types[type]->host.nv * 3;
+    C->hpos[type].resize(C->hpos[type].size() + add, 0.0); C->hvel[type].resize(C->hvel[type].size() + add, 0.0); C->hfrc[type].resize(C->hfrc[type].size() + add, 0.0);
+    for (int i = 0; i < n; i++) if (is_new[i]) C->hids[type].push_back(cell_ids[i]);
+    C->host_dirty = true;
+    rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  } else {
+    for (int i = 0; i < n; i++) if (is_new[i]) C->hids[type].push_back(cell_ids[i]);
+    C->ncells[type] += n_new;
+    C->nverts += n_new * C->types[type]->host.nv;
+  }
+  int *d_slots = nullptr, *d_new = nullptr;
+  rc = stage_ints(C, 0, &d_slots, slots, n); if (rc != HC_OK) return rc;
+  rc = stage_ints(C, 1, &d_new, is_new, n); if (rc != HC_OK) return rc;
+  hipLaunchKernelGGL(unpack_cells_kernel, dim3((unsigned)n), dim3(256), 0, hc::stream(), C->types[type]->host.nv, C->rep_on() ? 12 : 9, (const int *)d_slots, (const int *)d_new,
+                     vert_arrays(C, type), dev_buf, C->L->x0, C->L->nx);
+  HC_HIP(hipGetLastError());
+  return HC_OK;
+}
+
+int hcp_remove_cells(hc_cells *C, int type, const int *slots, int n) {
+  HC_REQUIRE(C && type >= 0 && type < C->ntypes && n >= 0, "hcp_remove_cells: bad arguments");
+  if (n == 0) return HC_OK;
+  HC_REQUIRE(slots, "hcp_remove_cells: null pointer");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  const long nc = C->ncells[type], new_nc = nc - n;
+  std::vector<char> dead((size_t)nc, 0);
+  for (int i = 0; i < n; i++) { HC_REQUIRE(slots[i] >= 0 && slots[i] < nc && !dead[(size_t)slots[i]], "hcp_remove_cells: bad slot list"); dead[(size_t)slots[i]] = 1; }
+  // holes below new_nc are filled with the live cells at and above new_nc (disjoint ranges: no hazard)
+  std::vector<int> src, dst;
+  long tail = new_nc;
+  for (long h = 0; h < new_nc; h++) {
+    if (!dead[(size_t)h]) continue;
+    while (tail < nc && dead[(size_t)tail]) tail++;
+    src.push_back((int)tail); dst.push_back((int)h);
+    C->hids[type][(size_t)h] = C->hids[type][(size_t)tail];
+    tail++;
+  }
+  C->hids[type].resize((size_t)new_nc);
+  if (!src.empty()) {
+    int *d_src = nullptr, *d_dst = nullptr;
+    rc = stage_ints(C, 0, &d_src, src.data(), (int)src.size()); if (rc != HC_OK) return rc;
+    rc = stage_ints(C, 1, &d_dst, dst.data(), (int)dst.size()); if (rc != HC_OK) return rc;
+    hipLaunchKernelGGL(move_cells_kernel, dim3((unsigned)src.size()), dim3(256), 0, hc::stream(), C->types[type]->host.nv, (const int *)d_src, (const int *)d_dst, vert_arrays(C, type));
+    HC_HIP(hipGetLastError());
+  }
+  C->ncells[type] = new_nc;
+  C->nverts -= (long)n * C->types[type]->host.nv;
+  return HC_OK;
+}
+
+int hcp_owned_vertices(hc_cells *C, long *n_owned) {
+  HC_REQUIRE(C && n_owned, "hcp_owned_vertices: null pointer");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  unsigned long long *d = nullptr, h = 0;
+  HC_HIP(hipMalloc((void **)&d, sizeof(unsigned long long)));
+  HC_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), hc::stream()));
+  for (int t = 0; t < C->ntypes; t++) {
+    const long n = C->ncells[t] * C->types[t]->host.nv;
+    if (n == 0) continue;
+    hipLaunchKernelGGL(owned_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), n, (const double *)(C->pos[0] + C->first[t]), C->L->x0, C->L->nx, d);
+  }
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, hc::stream());
+  if (e == hipSuccess) e = hipStreamSynchronize(hc::stream());
+  hipFree(d);
+  if (e != hipSuccess) return hc::hip_fail(e, "hcp_owned_vertices", __FILE__, __LINE__);
+  *n_owned = (long)h;
+  return HC_OK;
+}
+
+
+// ParticleInfo::calculate{Velocity,Force}Statistics (helper/particleInfo.cpp:30-140) as a device reduction
+int hcp_vertex_stats(hc_cells *C, int what, double out[3], long *n) {
+  HC_REQUIRE(C && out && n && (what == 1 || what == 2), "hcp_vertex_stats: bad arguments (what: 1 velocity, 2 force)");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  double *d_partial = nullptr;
+  HC_HIP(hipMalloc((void **)&d_partial, (size_t)STAT_BLOCKS * 4 * sizeof(double)));
+  HC_HIP(hipMemsetAsync(d_partial, 0, (size_t)STAT_BLOCKS * 4 * sizeof(double), hc::stream()));
+  const hc_lattice *L = C->L;
+  int launched = 0;
+  for (int t = 0; t < C->ntypes; t++) {
+    const long nt = C->ncells[t] * C->types[t]->host.nv, f = C->first[t];
+    if (nt == 0) continue;
+    double **src = what == 1 ? C->vel : C->frc;
+    hipLaunchKernelGGL(vertex_stats_kernel, dim3(STAT_BLOCKS), dim3(256), 0, hc::stream(), nt, what, L->n_slabs == 1 ? 1 : 0, L->x0, L->nx,
+                       (const double *)(C->pos[0] + f), (const double *)(src[0] + f), (const double *)(src[1] + f), (const double *)(src[2] + f),
+                       C->rep[0] ? (const double *)(C->rep[0] + f) : nullptr, C->rep[1] ? (const double *)(C->rep[1] + f) : nullptr,
+                       C->rep[2] ? (const double *)(C->rep[2] + f) : nullptr, d_partial, launched);
+    launched = 1;
+  }
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) rc = hc::stat_finish(d_partial, out, n);
+  hipFree(d_partial);
+  if (e != hipSuccess) return hc::hip_fail(e, "hcp_vertex_stats", __FILE__, __LINE__);
+  return rc;
+}
+
+
+}  // extern "C"

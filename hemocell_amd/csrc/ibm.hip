@@ -1,0 +1,432 @@
+// Immersed-boundary coupling on the GPU: phi2 force spreading and velocity interpolation.
+//
+// Replaces (file:line in the HemoCell tree):
+//   core/immersedBoundaryMethod.h:62-138          interpolationCoefficientsPhi2 (cells.h: phi2_stencil)
+//   core/hemoCellParticleField.cpp:841-863        spreadParticleForce
+//   core/hemoCellParticleField.cpp:819-839        interpolateFluidVelocity
+#include "cells.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------
+// spread
+__global__ __launch_bounds__(256) void ibm_spread_kernel(LatView v, long n, const double *px, const double *py, const double *pz,
+                                                         double *fx, double *fy, double *fz, const double *rx, const double *ry, const double *rz,
+                                                         double *F, int limit_on, double f_limit) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double f0 = fx[i], f1 = fy[i], f2 = fz[i];
+  if (limit_on) {  // FORCE_LIMIT cap, core/hemoCellParticleField.cpp:848-852 (mutates sv.force)
+    const double mag = sqrt((f0 * f0 + f1 * f1) + f2 * f2);
+    if (mag > f_limit) {
+      const double sc = f_limit / mag;
+      f0 *= sc; f1 *= sc; f2 *= sc;
+      fx[i] = f0; fy[i] = f1; fz[i] = f2;
+    }
+  }
+  Stencil s;
+  phi2_stencil(v, px[i], py[i], pz[i], s);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (s.node[k] < 0) continue;
+    v.dirty[s.node[k] >> 4] = v.epoch;
+    // external.data[d] += (force_repulsion[d] + force[d]) * weight  (:857-859)
+    unsafeAtomicAdd(&F[s.node[k]], ((rx ? rx[i] : 0.0) + f0) * s.w[k]);
+    unsafeAtomicAdd(&F[v.npad + s.node[k]], ((ry ? ry[i] : 0.0) + f1) * s.w[k]);
+    unsafeAtomicAdd(&F[2 * v.npad + s.node[k]], ((rz ? rz[i] : 0.0) + f2) * s.w[k]);
+  }
+}
+
+// ----------------------------------------------------------------------------
+// interpolate: v = sum_j w_j * (j/rho + F/2)(node_j) on the post-stream state
+struct PopView {
+  const double *f; const double *F; double bx, by, bz;
+};
+
+__device__ __forceinline__ void node_velocity(const LatView &v, const PopView &pv, int lx, int ly, int lz, long node, double u[3]) {
+  // gather S(node,q) = P(node - c_q, q) with the same wrap rules as the collide kernel
+  long xm = -(long)v.plane, xp = (long)v.plane;
+  if (v.wrap_x) { if (lx == 0) xm = (long)(v.nx - 1) * v.plane; if (lx == v.nx - 1) xp = -(long)(v.nx - 1) * v.plane; }
+  int ym = -v.nz, yp = v.nz, zm = -1, zp = 1; bool ymk = true, ypk = true, zmk = true, zpk = true;
+  if (ly == 0) { if (v.per_y) ym = (v.ny - 1) * v.nz; else ymk = false; }
+  if (ly == v.ny - 1) { if (v.per_y) yp = -(v.ny - 1) * v.nz; else ypk = false; }
+  if (lz == 0) { if (v.per_z) zm = v.nz - 1; else zmk = false; }
+  if (lz == v.nz - 1) { if (v.per_z) zp = -(v.nz - 1); else zpk = false; }
+  double r = 0.0, jx = 0.0, jy = 0.0, jz = 0.0;
+#define M(Q, CX, CY, CZ)                                                              \
+  {                                                                                   \
+    long off = 0; bool ok = true;                                                     \
+    if (CX == 1) off += xm; else if (CX == -1) off += xp;                             \
+    if (CY == 1) { off += ym; ok = ok && ymk; } else if (CY == -1) { off += yp; ok = ok && ypk; } \
+    if (CZ == 1) { off += zm; ok = ok && zmk; } else if (CZ == -1) { off += zp; ok = ok && zpk; } \
+    const double fq = ok ? pv.f[(long)Q * v.npad + node + off] : 0.0;                 \
+    r += fq;                                                                          \
+    if (CX == 1) jx += fq; else if (CX == -1) jx += -fq;                              \
+    if (CY == 1) jy += fq; else if (CY == -1) jy += -fq;                              \
+    if (CZ == 1) jz += fq; else if (CZ == -1) jz += -fq;                              \
+  }
+  M(0, 0, 0, 0) M(1, -1, 0, 0) M(2, 0, -1, 0) M(3, 0, 0, -1) M(4, -1, -1, 0) M(5, -1, 1, 0)
+  M(6, -1, 0, -1) M(7, -1, 0, 1) M(8, 0, -1, -1) M(9, 0, -1, 1) M(10, 1, 0, 0) M(11, 0, 1, 0)
+  M(12, 0, 0, 1) M(13, 1, 1, 0) M(14, 1, -1, 0) M(15, 1, 0, 1) M(16, 1, 0, -1) M(17, 0, 1, 1)
+  M(18, 0, 1, -1)
+#undef M
+  const double invRho = 1.0 / (1.0 + r);
+  u[0] = jx * invRho + (pv.bx + pv.F[node]) / 2.0;
+  u[1] = jy * invRho + (pv.by + pv.F[v.npad + node]) / 2.0;
+  u[2] = jz * invRho + (pv.bz + pv.F[2 * v.npad + node]) / 2.0;
+}
+
+__global__ __launch_bounds__(256) void ibm_interpolate_kernel(LatView v, PopView pv, long n, const double *px, const double *py,
+                                                              const double *pz, double *vx, double *vy, double *vz) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  Stencil s;
+  phi2_stencil(v, px[i], py[i], pz[i], s);
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (s.node[k] < 0) continue;
+    double u[3];
+    node_velocity(v, pv, s.lx[k], s.ly[k], s.lz[k], s.node[k], u);
+    a0 += (u[0] * s.w[k]); a1 += (u[1] * s.w[k]); a2 += (u[2] * s.w[k]);
+  }
+  vx[i] = a0; vy[i] = a1; vz[i] = a2;
+}
+
+
+// ----------------------------------------------------------------------------
+// LDS-tiled IBM kernels: one workgroup per cell.
+//
+// All 8-node stencils of a cell fall into the cell's bounding box (+1).  Spread: the workgroup
+// accumulates one force component at a time on an LDS tile of that box (ds_add_f64), then flushes only the
+// touched nodes to HBM with one fp64 atomic each, z-contiguous -- several times fewer, better shaped
+// global atomics than one per (vertex, node, component).  Interpolate: the nodes the cell touches are
+// compacted, the node velocity (19-population gather + moments) is evaluated once per node into LDS, and
+// every vertex then blends its 8 values from LDS.
+constexpr int TILE_CAP = 5832;       // nodes per tile: 18 x 18 x 18, any orientation of a 642-vertex RBC; three workgroups per CU fit the 160 KB LDS
+constexpr int NODE_CAP = 1536;       // distinct nodes of one cell for the interpolation (an RBC touches ~1300)
+
+// bounding box of a cell's stencil nodes: origin o (global), extent e, origin ow in local wrapped coordinates,
+// reciprocals for the index decode
+struct Tile { int o[3]; int e[3]; int vol; int ow[3]; float r1, r2; };
+
+// tile index -> (tx, ty, tz) without integer division.  Exact for i < 2^16: (i + 0.5) / e is at least 0.5 / e
+// away from an integer while the float error stays below 1e-3 / e.
+__device__ __forceinline__ void tile_decode(const Tile &t, int i, int &tx, int &ty, int &tz) {
+  const int q = (int)(((float)i + 0.5f) * t.r2);
+  tz = i - q * t.e[2];
+  tx = (int)(((float)q + 0.5f) * t.r1);
+  ty = q - tx * t.e[1];
+}
+
+__device__ __forceinline__ int stencil_base(const LatView &v, double px, double py, double pz, int b[3]) {
+  const double p[3] = {px, py, pz};
+#pragma unroll
+  for (int a = 0; a < 3; a++) { const long c = nearest_node(p[a]); b[a] = (int)c + ((p[a] < (double)c) ? -1 : 0); }
+  return 0;
+}
+
+// global lattice element of tile entry i (only meaningful for entries that were admitted by a stencil)
+__device__ __forceinline__ long tile_node(const LatView &v, const Tile &t, int i, int &lx, int &ly, int &lz) {
+  int tx, ty, tz;
+  tile_decode(t, i, tx, ty, tz);
+  lx = t.ow[0] + tx; ly = t.ow[1] + ty; lz = t.ow[2] + tz;
+  if (v.wrap_x && lx >= v.nx) lx -= v.nx;     // the tile is no wider than the domain (cell_prologue), one wrap suffices
+  if (v.per_y && ly >= v.ny) ly -= v.ny;
+  if (v.per_z && lz >= v.nz) lz -= v.nz;
+  return (long)(lx + HALO) * v.plane + ly * v.nz + lz;
+}
+
+// compact per-vertex stencil kept in registers across the passes of the cell kernels
+struct VStencil { double w[8]; int base; unsigned adm; };   // base = tile index of the lowest corner; adm = admitted-node bits
+
+constexpr int NVPT = 3;        // vertices per thread held in registers (642 vertices / 256 threads)
+constexpr int MAXW = 4;        // waves per workgroup
+
+// bounding box of all stencil nodes of the cell: per-thread min/max -> wave shuffles -> LDS -> everyone
+__device__ __forceinline__ void block_bbox(int lo[3], int hi[3], int *s_red, Tile &t) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { lo[a] = min(lo[a], __shfl_xor(lo[a], off)); hi[a] = max(hi[a], __shfl_xor(hi[a], off)); }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) { s_red[(tid >> 6) * 6 + a] = lo[a]; s_red[(tid >> 6) * 6 + 3 + a] = hi[a]; }
+  }
+  __syncthreads();
+  const int nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    int l = s_red[a], h = s_red[3 + a];
+    for (int w = 1; w < nw; w++) { l = min(l, s_red[w * 6 + a]); h = max(h, s_red[w * 6 + 3 + a]); }
+    t.o[a] = l; t.e[a] = h - l + 1;
+  }
+  const long vol = (long)t.e[0] * t.e[1] * t.e[2];
+  t.vol = vol > 0x7fffffff ? 0x7fffffff : (int)vol;
+}
+
+// local (wrapped) origin and decode reciprocals; false when the tile cannot be used
+__device__ __forceinline__ bool tile_finish(const LatView &v, Tile &t) {
+  if (t.vol > TILE_CAP) return false;
+  if ((v.wrap_x && t.e[0] > v.nx) || (v.per_y && t.e[1] > v.ny) || (v.per_z && t.e[2] > v.nz)) return false;
+  t.ow[0] = v.wrap_x ? (int)pmod((long)t.o[0] - v.x0, v.nx) : t.o[0] - v.x0;
+  t.ow[1] = v.per_y ? (int)pmod(t.o[1], v.ny) : t.o[1];
+  t.ow[2] = v.per_z ? (int)pmod(t.o[2], v.nz) : t.o[2];
+  t.r1 = 1.0f / (float)t.e[1]; t.r2 = 1.0f / (float)t.e[2];
+  return true;
+}
+
+// mask class of tile entry i: 0 fluid, 1/2 boundary, 3 not addressable (outside the domain / halo range)
+__device__ __forceinline__ unsigned char tile_mask(const LatView &v, const Tile &t, int i) {
+  int tx, ty, tz;
+  tile_decode(t, i, tx, ty, tz);
+  int lx = t.ow[0] + tx, ly = t.ow[1] + ty, lz = t.ow[2] + tz;
+  if (v.wrap_x) { if (lx >= v.nx) lx -= v.nx; }
+  else if (v.halo_x) { if (lx < -HALO || lx >= v.nx + HALO) return 3; }
+  else if (lx < 0 || lx >= v.nx) return 3;
+  if (v.per_y) { if (ly >= v.ny) ly -= v.ny; } else if (ly < 0 || ly >= v.ny) return 3;
+  if (v.per_z) { if (lz >= v.nz) lz -= v.nz; } else if (lz < 0 || lz >= v.nz) return 3;
+  return v.mask[(long)(lx + HALO) * v.plane + ly * v.nz + lz];
+}
+
+// interpolationCoefficientsPhi2 against the LDS copy of the mask; same arithmetic and visiting order as phi2_stencil
+__device__ __forceinline__ void tile_stencil(const Tile &t, const unsigned char *mt, double px, double py, double pz, const int b[3], VStencil &o) {
+  const int sy = t.e[2], sx = t.e[1] * t.e[2];
+  o.base = ((b[0] - t.o[0]) * t.e[1] + (b[1] - t.o[1])) * t.e[2] + (b[2] - t.o[2]);
+  o.adm = 0;
+  double total = 0.0;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int idx = i * 4 + j * 2 + k;
+        const double weight = phi2(px - (double)(b[0] + i)) * phi2(py - (double)(b[1] + j)) * phi2(pz - (double)(b[2] + k));
+        const bool adm = (weight != 0.0) && (mt[o.base + i * sx + j * sy + k] == 0);
+        if (adm) { total += weight; o.adm |= 1u << idx; }
+        o.w[idx] = adm ? weight : 0.0;
+      }
+  const double coeff = 1.0 / total;
+#pragma unroll
+  for (int idx = 0; idx < 8; idx++) o.w[idx] *= coeff;
+}
+
+// shared prologue of the two cell kernels: positions -> registers, tile, mask tile, stencils.
+// returns false (uniformly) when the cell does not fit the tile and the caller must take the fallback path
+__device__ __forceinline__ bool cell_prologue(const LatView &v, int nv, long base, const double *px, const double *py, const double *pz,
+                                              int *s_red, unsigned char *mt, Tile &t, VStencil vs[NVPT]) {
+  const int tid = threadIdx.x, nth = blockDim.x;
+  double p[NVPT][3]; int b[NVPT][3];
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
+#pragma unroll
+  for (int j = 0; j < NVPT; j++) {
+    const int i = tid + j * nth;
+    if (i < nv) {
+      p[j][0] = px[base + i]; p[j][1] = py[base + i]; p[j][2] = pz[base + i];
+      stencil_base(v, p[j][0], p[j][1], p[j][2], b[j]);
+#pragma unroll
+      for (int a = 0; a < 3; a++) { lo[a] = min(lo[a], b[j][a]); hi[a] = max(hi[a], b[j][a] + 1); }
+    }
+  }
+  block_bbox(lo, hi, s_red, t);
+  if (!tile_finish(v, t) || nv > NVPT * nth) return false;
+#pragma unroll 4
+  for (int i = tid; i < t.vol; i += nth) mt[i] = tile_mask(v, t, i);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NVPT; j++) {
+    vs[j].adm = 0;
+    if (tid + j * nth < nv) tile_stencil(t, mt, p[j][0], p[j][1], p[j][2], b[j], vs[j]);
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv, const double *px, const double *py, const double *pz,
+                                                              double *fx, double *fy, double *fz, const double *rx, const double *ry, const double *rz,
+                                                              double *F, int limit_on, double f_limit) {
+  __shared__ double tile[TILE_CAP];
+  __shared__ unsigned char mt[TILE_CAP];
+  __shared__ int s_red[6 * MAXW];
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const long base = (long)blockIdx.x * nv;
+  // FORCE_LIMIT cap, core/hemoCellParticleField.cpp:848-852 (mutates sv.force)
+  if (limit_on) {
+    for (int i = tid; i < nv; i += nth) {
+      const double f0 = fx[base + i], f1 = fy[base + i], f2 = fz[base + i];
+      const double mag = sqrt((f0 * f0 + f1 * f1) + f2 * f2);
+      if (mag > f_limit) { const double sc = f_limit / mag; fx[base + i] = f0 * sc; fy[base + i] = f1 * sc; fz[base + i] = f2 * sc; }
+    }
+  }
+  Tile t; VStencil vs[NVPT];
+  if (!cell_prologue(v, nv, base, px, py, pz, s_red, mt, t, vs)) {
+    // cell larger than the tile (or mesh larger than the register budget): direct global atomics
+    for (int i = tid; i < nv; i += nth) {
+      Stencil s;
+      phi2_stencil(v, px[base + i], py[base + i], pz[base + i], s);
+      const double f0 = (rx ? rx[base + i] : 0.0) + fx[base + i], f1 = (ry ? ry[base + i] : 0.0) + fy[base + i], f2 = (rz ? rz[base + i] : 0.0) + fz[base + i];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        if (s.node[k] < 0) continue;
+        v.dirty[s.node[k] >> 4] = v.epoch;
+        unsafeAtomicAdd(&F[s.node[k]], f0 * s.w[k]);
+        unsafeAtomicAdd(&F[v.npad + s.node[k]], f1 * s.w[k]);
+        unsafeAtomicAdd(&F[2 * v.npad + s.node[k]], f2 * s.w[k]);
+      }
+    }
+    return;
+  }
+  const int sy = t.e[2], sx = t.e[1] * t.e[2];
+  for (int comp = 0; comp < 3; comp++) {
+    const double *fc = comp == 0 ? fx : comp == 1 ? fy : fz;
+    const double *rc = comp == 0 ? rx : comp == 1 ? ry : rz;
+    double *Fc = F + (long)comp * v.npad;
+    for (int i = tid; i < t.vol; i += nth) tile[i] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NVPT; j++) {
+      const int i = tid + j * nth;
+      if (i >= nv) continue;
+      const double f = (rc ? rc[base + i] : 0.0) + fc[base + i];   // force_repulsion + force, :857-859
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (vs[j].adm & (1u << k)) atomicAdd(&tile[vs[j].base + (k >> 2) * sx + ((k >> 1) & 1) * sy + (k & 1)], f * vs[j].w[k]);
+    }
+    __syncthreads();
+    for (int i = tid; i < t.vol; i += nth) {
+      const double val = tile[i];
+      if (val != 0.0) { int lx, ly, lz; const long node = tile_node(v, t, i, lx, ly, lz); v.dirty[node >> 4] = v.epoch; unsafeAtomicAdd(&Fc[node], val); }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void ibm_interpolate_cell_kernel(LatView v, PopView pv, int nv, const double *px, const double *py,
+                                                                   const double *pz, double *vx, double *vy, double *vz) {
+  // 54 KB in all, so that three workgroups share a CU: 16-bit slots, and the node list reuses the mask tile
+  // (the mask is only read while the stencils are formed)
+  constexpr unsigned short FREE = 0xFFFF, MARK = 0xFFFE;
+  __shared__ unsigned short slot[TILE_CAP];
+  __shared__ __attribute__((aligned(16))) unsigned char raw[TILE_CAP > 2 * NODE_CAP ? TILE_CAP : 2 * NODE_CAP];
+  unsigned char *mt = raw; unsigned short *list = reinterpret_cast<unsigned short *>(raw);
+  __shared__ double ux[NODE_CAP], uy[NODE_CAP], uz[NODE_CAP];
+  __shared__ int s_red[6 * MAXW], s_count;
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const long base = (long)blockIdx.x * nv;
+  Tile t; VStencil vs[NVPT];
+  bool tiled = cell_prologue(v, nv, base, px, py, pz, s_red, mt, t, vs);
+  const int sy = t.e[2], sx = t.e[1] * t.e[2];
+  if (tiled) {
+    for (int i = tid; i < t.vol; i += nth) slot[i] = FREE;
+    if (tid == 0) s_count = 0;
+    __syncthreads();   // also: every thread is done reading mt, list may overwrite it
+#pragma unroll
+    for (int j = 0; j < NVPT; j++)   // mark the admitted nodes
+#pragma unroll
+      for (int k = 0; k < 8; k++) if (vs[j].adm & (1u << k)) slot[vs[j].base + (k >> 2) * sx + ((k >> 1) & 1) * sy + (k & 1)] = MARK;
+    __syncthreads();
+    for (int i = tid; i < t.vol; i += nth) {   // compact
+      if (slot[i] == MARK) { const int n = atomicAdd(&s_count, 1); if (n < NODE_CAP) { slot[i] = (unsigned short)n; list[n] = (unsigned short)i; } }
+    }
+    __syncthreads();
+    if (s_count > NODE_CAP) tiled = false;   // uniform: s_count is shared
+  }
+  if (tiled) {
+    const int n = s_count;
+    for (int k = tid; k < n; k += nth) {       // node velocity once per node
+      int lx, ly, lz;
+      const long node = tile_node(v, t, list[k], lx, ly, lz);
+      double u[3];
+      node_velocity(v, pv, lx, ly, lz, node, u);
+      ux[k] = u[0]; uy[k] = u[1]; uz[k] = u[2];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NVPT; j++) {
+      const int i = tid + j * nth;
+      if (i >= nv) continue;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        if (!(vs[j].adm & (1u << k))) continue;
+        const int q = slot[vs[j].base + (k >> 2) * sx + ((k >> 1) & 1) * sy + (k & 1)];
+        a0 += (ux[q] * vs[j].w[k]); a1 += (uy[q] * vs[j].w[k]); a2 += (uz[q] * vs[j].w[k]);
+      }
+      vx[base + i] = a0; vy[base + i] = a1; vz[base + i] = a2;
+    }
+    return;
+  }
+  for (int i = tid; i < nv; i += nth) {   // fallback: per-vertex gathers
+    Stencil s;
+    phi2_stencil(v, px[base + i], py[base + i], pz[base + i], s);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (s.node[k] < 0) continue;
+      double u[3];
+      node_velocity(v, pv, s.lx[k], s.ly[k], s.lz[k], s.node[k], u);
+      a0 += (u[0] * s.w[k]); a1 += (u[1] * s.w[k]); a2 += (u[2] * s.w[k]);
+    }
+    vx[base + i] = a0; vy[base + i] = a1; vz[base + i] = a2;
+  }
+}
+
+}  // namespace
+
+static int g_ibm_per_vertex = 0;  // 1: one thread per vertex with direct global atomics (kept for A/B and as reference)
+extern "C" int hc_debug_ibm_per_vertex(int on) { g_ibm_per_vertex = on; return HC_OK; }
+
+extern "C" {
+
+int hcp_spread(hc_cells *C, int force_limit) {
+  HC_REQUIRE(C, "hcp_spread: null pointer");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  if (C->nverts == 0) return HC_OK;
+  hc::ProfScope prof(hc::PK_SPREAD);
+  const LatView v = make_view(C->L);
+  for (int t = 0; t < C->ntypes; t++) {
+    const long n = C->ncells[t] * C->types[t]->host.nv, f = C->first[t];
+    if (n == 0) continue;
+    const int nv = C->types[t]->host.nv;
+    const double *rp[3] = {C->rep_on() ? C->rep[0] + f : nullptr, C->rep_on() ? C->rep[1] + f : nullptr, C->rep_on() ? C->rep[2] + f : nullptr};
+    if (g_ibm_per_vertex)
+      hipLaunchKernelGGL(ibm_spread_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), v, n,
+                         (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
+                         C->frc[0] + f, C->frc[1] + f, C->frc[2] + f, rp[0], rp[1], rp[2], C->L->force[C->L->fcur], force_limit, C->P.f_limit);
+    else
+      hipLaunchKernelGGL(ibm_spread_cell_kernel, dim3((unsigned)C->ncells[t]), dim3(nv > 128 ? 256 : 128), 0, hc::stream(), v, nv,
+                         (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
+                         C->frc[0] + f, C->frc[1] + f, C->frc[2] + f, rp[0], rp[1], rp[2], C->L->force[C->L->fcur], force_limit, C->P.f_limit);
+    HC_HIP(hipGetLastError());
+  }
+  return HC_OK;
+}
+
+int hcp_interpolate(hc_cells *C) {
+  HC_REQUIRE(C, "hcp_interpolate: null pointer");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  if (C->nverts == 0) return HC_OK;
+  hc::ProfScope prof(hc::PK_INTERP);
+  const hc_lattice *L = C->L;
+  const LatView v = make_view(L);
+  // state after hcl_step_end: f[cur] holds the populations just written, force[1-fcur] the force they were collided with
+  PopView pv{L->f[L->cur], L->force[1 - L->fcur], L->body[0], L->body[1], L->body[2]};
+  for (int t = 0; t < C->ntypes; t++) {
+    const long n = C->ncells[t] * C->types[t]->host.nv, f = C->first[t];
+    if (n == 0) continue;
+    const int nv = C->types[t]->host.nv;
+    if (g_ibm_per_vertex)
+      hipLaunchKernelGGL(ibm_interpolate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), v, pv, n,
+                         (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
+                         C->vel[0] + f, C->vel[1] + f, C->vel[2] + f);
+    else
+      hipLaunchKernelGGL(ibm_interpolate_cell_kernel, dim3((unsigned)C->ncells[t]), dim3(nv > 128 ? 256 : 128), 0, hc::stream(), v, pv, nv,
+                         (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
+                         C->vel[0] + f, C->vel[1] + f, C->vel[2] + f);
+    HC_HIP(hipGetLastError());
+  }
+  return HC_OK;
+}
+
+}  // extern "C"

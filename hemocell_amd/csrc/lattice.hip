@@ -329,16 +329,17 @@ struct HaloArgs {
   double *f;          // population buffer
   double *buf;        // contiguous staging
   long npad; int plane;
-  int npops; int pops[HC_Q];
-  int width; int x_first;   // padded x index of the first plane
+  int n;              // (population, plane) entries
+  int pop[HC_Q + 5];  // population of entry e
+  int xp[HC_Q + 5];   // padded x index of its plane
   int to_buf;
 };
 __global__ void halo_copy_kernel(HaloArgs h) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= h.plane) return;
-  const int w = blockIdx.y % h.width, k = blockIdx.y / h.width;
-  const long li = (long)h.pops[k] * h.npad + (long)(h.x_first + w) * h.plane + p;
-  const long bi = ((long)k * h.width + w) * h.plane + p;
+  const int e = blockIdx.y;
+  const long li = (long)h.pop[e] * h.npad + (long)h.xp[e] * h.plane + p;
+  const long bi = (long)e * h.plane + p;
   if (h.to_buf) h.buf[bi] = h.f[li]; else h.f[li] = h.buf[bi];
 }
 
@@ -666,9 +667,12 @@ int hcl_fluid_stats(hc_lattice *L, int what, double out[3], long *n_nodes) {
 
 size_t hcl_halo_doubles(const hc_lattice *L, int width) {
   if (!L) return 0;
-  return (size_t)(width == 1 ? 5 : HC_Q) * (size_t)width * L->plane;
+  return (size_t)(width == 1 ? 5 : HC_Q + 5) * L->plane;
 }
 
+// width 1 (every step): the 5 populations that cross the face.  width 2 (before interpolation): everything the
+// neighbour needs to evaluate node velocities on its first halo plane -- all 19 populations of the face plane plus,
+// from the plane behind it, the 5 that stream onto that halo plane.
 static int halo_copy(hc_lattice *L, int side, int width, double *buf, int to_buf) {
   HC_REQUIRE(L && buf, "hcl_halo: null pointer");
   HC_REQUIRE((side == 0 || side == 1) && (width == 1 || width == 2), "hcl_halo: side must be 0/1 and width 1/2");
@@ -676,20 +680,20 @@ static int halo_copy(hc_lattice *L, int side, int width, double *buf, int to_buf
   static const int cxm[5] = {1, 4, 5, 6, 7};        // c_x = -1
   static const int cxp[5] = {10, 13, 14, 15, 16};   // c_x = +1
   HaloArgs h;
-  h.f = L->f[L->cur]; h.buf = buf; h.npad = (long)L->npad; h.plane = (int)L->plane; h.width = width; h.to_buf = to_buf;
-  if (width == 2) { h.npops = HC_Q; for (int q = 0; q < HC_Q; q++) h.pops[q] = q; }
-  else {
-    h.npops = 5;
-    // pack low face: the low neighbour pulls c_x=-1 populations from x+1 -> send c_x=-1 of plane 0
-    // pack high face: send c_x=+1 of plane nx-1
-    // unpack low halo (plane -1): receives the low neighbour's high face -> c_x=+1
-    // unpack high halo (plane nx): receives c_x=-1
-    const int *src = to_buf ? (side == 0 ? cxm : cxp) : (side == 0 ? cxp : cxm);
-    for (int k = 0; k < 5; k++) h.pops[k] = src[k];
+  h.f = L->f[L->cur]; h.buf = buf; h.npad = (long)L->npad; h.plane = (int)L->plane; h.to_buf = to_buf; h.n = 0;
+  // the populations that travel towards -x (cxm) leave through the low face and arrive in the low neighbour's high
+  // halo; those towards +x (cxp) the other way round
+  const int *moving = to_buf ? (side == 0 ? cxm : cxp) : (side == 0 ? cxp : cxm);
+  // plane next to the face (bulk side when packing, halo side when unpacking) and the one behind it
+  const int near = to_buf ? (side == 0 ? HALO : HALO + L->nx - 1) : (side == 0 ? HALO - 1 : HALO + L->nx);
+  const int far = to_buf ? (side == 0 ? HALO + 1 : HALO + L->nx - 2) : (side == 0 ? HALO - 2 : HALO + L->nx + 1);
+  if (width == 1) {
+    for (int k = 0; k < 5; k++) { h.pop[h.n] = moving[k]; h.xp[h.n] = near; h.n++; }
+  } else {
+    for (int q = 0; q < HC_Q; q++) { h.pop[h.n] = q; h.xp[h.n] = near; h.n++; }
+    for (int k = 0; k < 5; k++) { h.pop[h.n] = moving[k]; h.xp[h.n] = far; h.n++; }
   }
-  if (to_buf) h.x_first = (side == 0) ? HALO : HALO + L->nx - width;
-  else h.x_first = (side == 0) ? HALO - width : HALO + L->nx;
-  hipLaunchKernelGGL(halo_copy_kernel, dim3((unsigned)((L->plane + 255) / 256), (unsigned)(h.npops * width), 1), dim3(256), 0, hc::stream(), h);
+  hipLaunchKernelGGL(halo_copy_kernel, dim3((unsigned)((L->plane + 255) / 256), (unsigned)h.n, 1), dim3(256), 0, hc::stream(), h);
   HC_HIP(hipGetLastError());
   return HC_OK;
 }

@@ -299,13 +299,20 @@ __global__ void force_aos_kernel(LatArgs a, double *F) {
 }
 
 // FluidInfo statistics (helper/fluidInfo.cpp:33-96): magnitude of Cell::computeVelocity (what 0) or of the external
-// force (what 1) over the non-boundary bulk nodes
+// force (what 1) over the non-boundary bulk nodes; what 2: rhoBar = sum of the 19 stored populations, all bulk nodes
 __global__ __launch_bounds__(256) void fluid_stats_kernel(LatArgs a, int what, double *partial) {
   StatAcc acc{1e300, -1e300, 0.0, 0};
   const long nbulk = (long)a.nx * a.plane;
   for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nbulk; k += (long)STAT_BLOCKS * 256) {
     const int x = (int)(k / a.plane), p = (int)(k - (long)x * a.plane);
     const long node = (long)(x + HALO) * a.plane + p;
+    if (what == 2) {   // mass: sum of the stored populations of EVERY bulk node (walls park what bounces back)
+      double r = 0.0;
+#pragma unroll
+      for (int q = 0; q < HC_Q; q++) r += a.fin[(long)q * a.npad + node];
+      stat_add(acc, r);
+      continue;
+    }
     if (a.mask[node] != 0) continue;
     double Fx = a.bx, Fy = a.by, Fz = a.bz;
     if (a.ibm) { Fx = a.bx + a.Fin[node]; Fy = a.by + a.Fin[a.npad + node]; Fz = a.bz + a.Fin[2 * a.npad + node]; }
@@ -657,7 +664,7 @@ int hcl_zero_ibm_force(hc_lattice *L) {
 }
 
 int hcl_fluid_stats(hc_lattice *L, int what, double out[3], long *n_nodes) {
-  HC_REQUIRE(L && out && n_nodes && (what == 0 || what == 1), "hcl_fluid_stats: bad arguments");
+  HC_REQUIRE(L && out && n_nodes && what >= 0 && what <= 2, "hcl_fluid_stats: bad arguments");
   int rc = ensure_scratch(L, (size_t)STAT_BLOCKS * 4); if (rc != HC_OK) return rc;
   LatArgs a = make_args(L);
   hipLaunchKernelGGL(fluid_stats_kernel, dim3(STAT_BLOCKS), dim3(256), 0, hc::stream(), a, what, L->scratch);

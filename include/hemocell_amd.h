@@ -89,7 +89,8 @@ int hcl_download_rho_u(hc_lattice *L, double *rho, double *u);
 /* IBM force field currently accumulated (without the body force), [node][3] */
 /* FluidInfo::calculate{Velocity,Force}Statistics (helper/fluidInfo.cpp:33-118) as a device reduction: out = {min, max,
  * sum} of the magnitude over the non-boundary bulk nodes of this slab, *n_nodes their number.  what: 0 =
- * Cell::computeVelocity, 1 = external force (body force + the IBM field spread for the coming step).  Deterministic. */
+ * Cell::computeVelocity, 1 = external force (body force + the IBM field spread for the coming step), 2 = rhoBar (sum of
+ * the 19 stored populations) over ALL bulk nodes, walls included: its sum is the conserved mass.  Deterministic. */
 int hcl_fluid_stats(hc_lattice *L, int what, double out[3], long *n_nodes);
 int hcl_download_ibm_force(hc_lattice *L, double *F);
 int hcl_zero_ibm_force(hc_lattice *L);

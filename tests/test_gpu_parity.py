@@ -615,3 +615,111 @@ def test_info_reductions_match_downloaded_fields(gpu):
         assert n == len(m) and mn == m.min() and mx == m.max() and abs(avg - m.mean()) <= 1e-14 * m.mean()
         assert cf.vertex_stats(what) == (mn, mx, avg, n)
     L.destroy()
+
+
+def test_empty_and_degenerate_inputs(orc, gpu):
+    """edge cases: a cell field without cells, statistics over nothing, a lattice of the minimum size, a lattice
+    that is solid everywhere; none of them may fail or disturb the fluid"""
+    P = gpu.base_parameters()
+    # (1) cell types registered, no cell placed: iterate == fluid-only stepping, bit for bit
+    nx, ny, nz = 10, 9, 11
+    rng = np.random.default_rng(5)
+    f0 = _random_populations(rng, nx * ny * nz)
+    out = []
+    for with_cells in (False, True):
+        L = gpu.Lattice(nx, ny, nz, (1, 1, 1), 1.0 / P.tau)
+        L.set_populations(f0); L.setExternalVector((1e-6, 2e-6, -1e-6))
+        if with_cells:
+            h = gpu.HemoCell(L, P)
+            h.cellfields.addCellType(gpu.CellType.rbc(P), 3); h.cellfields.addCellType(gpu.CellType.plt(P), 2)
+            h.cellfields.setRepulsion(2e-6, 0.7, 1); h.cellfields.enableBoundaryParticles(2e-6, 1.0, 1)
+            h.cellfields.applyConstitutiveModel(0, True)
+            h.iterate(7)
+            assert h.cellfields.counts() == (0, 0, 0)
+            assert h.cellfields.positions.shape == (0, 3)
+            assert h.cellfields.vertex_stats(2) == (0.0, 0.0, 0.0, 0)
+        else:
+            L.collideAndStream(7)
+        out.append(L.populations()); L.destroy()
+    assert np.array_equal(out[0], out[1])
+    # (2) smallest lattice the library accepts, against the oracle
+    Lo, Lg = _both_lattices(orc, gpu, 2, 2, 2, (1, 1, 1), 1.0 / 0.8)
+    f0 = _random_populations(rng, 8)
+    Lo.f[:] = f0; Lg.set_populations(f0)
+    Lo.set_force_uniform((1e-5, 0, 0)); Lg.setExternalVector((1e-5, 0, 0))
+    Lo.collide_stream(5); Lg.collideAndStream(5)
+    assert np.array_equal(Lg.populations(), Lo.f)
+    Lo.destroy(); Lg.destroy()
+    # (3) no fluid node at all: stepping is a no-op that must not fault; statistics see zero nodes
+    L = gpu.Lattice(6, 5, 7, (1, 0, 0), 1.0)
+    L.defineBounceBack(np.ones((6, 5, 7), np.uint8)); L.latticeEquilibrium()
+    L.collideAndStream(3)
+    assert L.fluid_stats(0)[3] == 0
+    assert np.isfinite(L.populations()).all()
+    L.destroy()
+
+
+def test_full_size_fluid_box_config5(gpu):
+    """BASELINE config 5 (cases/performance_testing: 512^3 fully periodic, tau = 1, uniform body force on all axes) at
+    full size, through size-independent properties: from rest the flow stays uniform -- every node has bit-identical
+    velocity -- and |u| after N steps is |F| (N + 1/2) (Guo forcing adds F per step to the momentum, computeVelocity
+    adds F/2)"""
+    n = 512
+    P = gpu.base_parameters(dt=-1.0)
+    assert P.tau == 1.0
+    L = gpu.Lattice(n, n, n, (1, 1, 1), 1.0)
+    L.latticeEquilibrium()
+    F = 1e-7
+    L.setExternalVector((F, F, F))
+    N = 20
+    L.collideAndStream(N)
+    mn, mx, avg, cnt = L.fluid_stats(0)
+    assert cnt == n ** 3
+    assert mn == mx                                            # uniform, bit for bit, over 134 M nodes
+    assert abs(mx - np.sqrt(3.0) * F * (N + 0.5)) <= 1e-9 * mx
+    L.destroy()
+
+
+def test_full_size_properties_config3(gpu):
+    """BASELINE config 3 (examples/pipeflow 512x256x256, 10 % Hct RBC + PLT) on one GPU, through size-independent
+    properties: mass conserved, no cell lost, cell volumes and areas stay at their equilibrium values, Sum(spread) =
+    Sum(vertex forces), platelets and RBCs both move down the pipe"""
+    from hemocell_amd.packing import pack_pipe_rbc
+    nx, ny, nz = 512, 256, 256
+    P = gpu.base_parameters()
+    mask, R = gpu.pipe_mask(nx, ny, nz)
+    L = gpu.Lattice(nx, ny, nz, (1, 0, 0), 1.0 / P.tau)
+    L.defineBounceBack(mask); L.latticeEquilibrium()
+    h = gpu.HemoCell(L, P)
+    Tr, Tp = gpu.CellType.rbc(P), gpu.CellType.plt(P)
+    h.cellfields.addCellType(Tr, 20); h.cellfields.addCellType(Tp, 20); h.setParticleVelocityUpdateTimeScaleSeparation(5)
+    h.deletion_check_every = 10
+    centres, angles = pack_pipe_rbc(nx, ny, nz, 0.10)
+    n_rbc = sum(h.cellfields.addCell(0, c, a, cell_id=i) for i, (c, a) in enumerate(zip(centres, angles)))
+    pick = np.arange(0, len(centres), 14)
+    pc = centres[pick] + np.array([9.5, 0.0, 0.0]); pc[:, 2] += np.where(pc[:, 2] > nz / 2, -4.6, 4.6)
+    n_plt = sum(h.cellfields.addCell(1, c, (90.0, 0.0, 0.0), cell_id=len(centres) + i) for i, c in enumerate(pc))
+    assert n_rbc > 3500 and n_plt > 200
+    cf = h.cellfields
+    cf.applyConstitutiveModel(0, True)
+    L.setExternalVector((2e-6, 0, 0))
+    m0 = L.fluid_stats(2)[2] * L.fluid_stats(2)[3]
+    cf.spreadParticleForce(True)
+    f = cf.forces
+    Fmn, Fmx, Favg, Fn = L.fluid_stats(1)                      # |body + spread| is at least the body force everywhere
+    assert Fn == int((mask == 0).sum()) and Fmn > 0
+    check = gpu.capi.check; check(gpu.capi.lib().hcl_zero_ibm_force(L.ptr))
+    h.iterate(60)
+    m1 = L.fluid_stats(2)[2] * L.fluid_stats(2)[3]
+    assert abs(m1 - m0) <= 1e-9                                # sum over 33.5 M nodes x 19 populations
+    assert cf.counts()[1] == n_rbc + n_plt and cf.counts()[2] == 0
+    for t, T in ((0, Tr), (1, Tp)):
+        info = cf.cell_info(t); tab = T.tables()
+        assert np.isfinite(info["volume"]).all()
+        assert np.abs(info["volume"] / tab["volume_eq"] - 1).max() < 0.01
+        assert np.abs(info["area"] / (tab["area_mean_eq"] * T.nt) - 1).max() < 0.02
+    vmn, vmx, vavg, vn = cf.vertex_stats(1)
+    assert vn == n_rbc * 642 + n_plt * 66 and np.isfinite(vmx)
+    v = cf.velocities
+    assert v[:n_rbc * 642, 0].mean() > 0 and v[n_rbc * 642:, 0].mean() > 0
+    L.destroy()

@@ -233,6 +233,9 @@ def main():
                          "bytes_per_node": bytes_per_node, "nodes_per_launch": launch_nodes, "avg_launch_ms": avg_ms,
                          "launches": n.value, "peak_source": "MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)"},
             "kernel_ms": prof,
+            # whole job against the HBM roofline of the whole step: MLUPS x algorithmic bytes per node update over the
+            # aggregate 8 TB/s of the GPUs used (north_star: >= 0.60 on the 512^3 pipe at 1 GPU)
+            "whole_step_hbm_frac": mlups * 1e6 * bytes_per_node / (8.0e12 * world),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)

@@ -52,6 +52,9 @@ struct hc_cells {
   bool rep_on() const { return rep_enabled || brep_enabled; }
   unsigned int *d_keys[2] = {nullptr, nullptr}; int *d_vals[2] = {nullptr, nullptr}; void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0; long sort_cap = 0;
   int *d_iscratch[2] = {nullptr, nullptr};   // staged slot lists of the envelope exchange (stream ordered, no sync)
+  // staging of hcp_add_vertex_force (called every iteration by the stretch drivers): pinned host block + device block
+  // [n indices | 3n force components], grown on demand; the event guards the pinned block against reuse in flight
+  char *h_vf = nullptr, *d_vf = nullptr; size_t vf_cap = 0; hipEvent_t vf_done = nullptr;
   size_t iscratch_cap[2] = {0, 0};
   long n_deleted = 0;
 };

@@ -246,6 +246,9 @@ int hcp_destroy(hc_cells *C) {
   if (C->h_ntag) hipHostFree(C->h_ntag);
   if (C->d_ntag) hipFree(C->d_ntag);
   if (C->d_bflag) hipFree(C->d_bflag);
+  if (C->h_vf) hipHostFree(C->h_vf);
+  if (C->d_vf) hipFree(C->d_vf);
+  if (C->vf_done) hipEventDestroy(C->vf_done);
   for (int k = 0; k < 2; k++) if (C->d_iscratch[k]) hipFree(C->d_iscratch[k]);
   delete C;
   return HC_OK;
@@ -382,26 +385,37 @@ int hcp_add_vertex_force(hc_cells *C, const long *vertex_index, int n, const dou
   HC_REQUIRE(C && vertex_index && f && n >= 0, "hcp_add_vertex_force: bad arguments");
   if (n == 0) return HC_OK;
   int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  const size_t bytes = (size_t)n * (sizeof(long) + 3 * sizeof(double));
+  if (bytes > C->vf_cap) {
+    HC_HIP(hipStreamSynchronize(hc::stream()));
+    if (C->h_vf) HC_HIP(hipHostFree(C->h_vf));
+    if (C->d_vf) HC_HIP(hipFree(C->d_vf));
+    C->h_vf = C->d_vf = nullptr; C->vf_cap = 0;
+    HC_HIP(hipHostMalloc((void **)&C->h_vf, 2 * bytes, hipHostMallocDefault));
+    HC_HIP(hipMalloc((void **)&C->d_vf, 2 * bytes));
+    C->vf_cap = 2 * bytes;
+    if (!C->vf_done) HC_HIP(hipEventCreateWithFlags(&C->vf_done, hipEventDisableTiming));
+  } else {
+    HC_HIP(hipEventSynchronize(C->vf_done));   // the previous call's copy has left the pinned block
+  }
   // vertex_index counts vertices in download order (types packed back to back); device regions have gaps
-  std::vector<long> dev_idx((size_t)n);
+  long *h_idx = reinterpret_cast<long *>(C->h_vf);
+  double *h_f = reinterpret_cast<double *>(C->h_vf + (size_t)n * sizeof(long));
   for (int i = 0; i < n; i++) {
     long v = vertex_index[i], packed0 = 0; bool found = false;
     for (int t = 0; t < C->ntypes && !found; t++) {
       const long nt = C->ncells[t] * C->types[t]->host.nv;
-      if (v >= packed0 && v < packed0 + nt) { dev_idx[(size_t)i] = C->first[t] + (v - packed0); found = true; }
+      if (v >= packed0 && v < packed0 + nt) { h_idx[i] = C->first[t] + (v - packed0); found = true; }
       packed0 += nt;
     }
     HC_REQUIRE(found, "hcp_add_vertex_force: vertex index out of range");
   }
-  long *d_idx = nullptr; double *d_f = nullptr;
-  HC_HIP(hipMalloc((void **)&d_idx, n * sizeof(long)));
-  HC_HIP(hipMalloc((void **)&d_f, 3 * n * sizeof(double)));
-  HC_HIP(hipMemcpyAsync(d_idx, dev_idx.data(), n * sizeof(long), hipMemcpyHostToDevice, hc::stream()));
-  HC_HIP(hipMemcpyAsync(d_f, f, 3 * n * sizeof(double), hipMemcpyHostToDevice, hc::stream()));
-  hipLaunchKernelGGL(add_vertex_force_kernel, dim3((n + 255) / 256), dim3(256), 0, hc::stream(), n, (const long *)d_idx, (const double *)d_f, C->frc[0], C->frc[1], C->frc[2]);
+  std::memcpy(h_f, f, (size_t)3 * n * sizeof(double));
+  HC_HIP(hipMemcpyAsync(C->d_vf, C->h_vf, bytes, hipMemcpyHostToDevice, hc::stream()));
+  HC_HIP(hipEventRecord(C->vf_done, hc::stream()));
+  hipLaunchKernelGGL(add_vertex_force_kernel, dim3((n + 255) / 256), dim3(256), 0, hc::stream(), n, (const long *)C->d_vf,
+                     (const double *)(C->d_vf + (size_t)n * sizeof(long)), C->frc[0], C->frc[1], C->frc[2]);
   HC_HIP(hipGetLastError());
-  HC_HIP(hipStreamSynchronize(hc::stream()));
-  hipFree(d_idx); hipFree(d_f);
   return HC_OK;
 }
 

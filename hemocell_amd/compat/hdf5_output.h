@@ -44,6 +44,17 @@ inline void writeCellField3D_HDF5(HemoCell &h, HemoCellField &field, const strin
   const long n = nc * field.numVertex;
   vector<double> pos(3 * (size_t)nvt), vel(3 * (size_t)nvt), frc(3 * (size_t)nvt), comp;
   if (nvt) { hcp_download(c, 0, pos.data()); hcp_download(c, 1, vel.data()); hcp_download(c, 2, frc.data()); }
+  vector<double> rep(3 * (size_t)nvt, 0.0);
+  if (nvt) hc_check(hcp_download_repulsion(c, rep.data()), "hcp_download_repulsion");   // zeros while no repulsion is enabled
+  // the reference writes each particle where its block holds it, i.e. inside the domain; positions here are not
+  // re-wrapped when a cell crosses a periodic face, so they are wrapped vertex by vertex for the output
+  {
+    const plint dims[3] = {h.lattice->getNx(), h.lattice->getNy(), h.lattice->getNz()};
+    for (int d = 0; d < 3; d++) {
+      if (!h.lattice->per.p[d]) continue;
+      for (long i = 0; i < nvt; i++) { double &x = pos[(size_t)(3 * i + d)]; x -= (double)dims[d] * std::floor((x + 0.5) / (double)dims[d]); }
+    }
+  }
   vector<long> ids((size_t)nct); if (nct) hcp_download_cell_ids(c, ids.data());
   long first_cell = 0; for (unsigned int t = 0; t < field.ctype; t++) { long f2, n2; hcp_type_range(c, (int)t, &f2, &n2); first_cell += n2; }
   const string fileName = dir + "/" + field.name + "." + zeroPadNumber(h.iter) + ".p.0.h5";
@@ -59,14 +70,16 @@ inline void writeCellField3D_HDF5(HemoCell &h, HemoCellField &field, const strin
     switch (var) {
       case OUTPUT_POSITION: { h5_write_2d(file, "Position", vec3(pos, si ? Parameters::dx : 1.0), n, 3); long nP = n; H5LTset_attribute_long(file, "/", "numberOfParticles", &nP, 1); break; }
       case OUTPUT_VELOCITY: h5_write_2d(file, "Velocity", vec3(vel, si ? Parameters::dx / Parameters::dt : 1.0), n, 3); break;
-      case OUTPUT_FORCE: h5_write_2d(file, "Total force", vec3(frc, si ? Parameters::df : 1.0), n, 3); break;
+      case OUTPUT_FORCE: {   // force_total = force + force_repulsion (core/hemoCellParticleField.cpp:596)
+        vector<double> tot(frc); for (size_t i = 0; i < tot.size(); i++) tot[i] += rep[i];
+        h5_write_2d(file, "Total force", vec3(tot, si ? Parameters::df : 1.0), n, 3); break; }
       case OUTPUT_FORCE_VOLUME: case OUTPUT_FORCE_AREA: case OUTPUT_FORCE_BENDING: case OUTPUT_FORCE_LINK: case OUTPUT_FORCE_VISC: case OUTPUT_FORCE_INNER_LINK: {
         if (comp.empty() && n) { comp.resize(18 * (size_t)n); hc_check(hcp_mechanics_components(c, (int)field.ctype, comp.data()), "hcp_mechanics_components"); }
         const int slot = var == OUTPUT_FORCE_VOLUME ? 0 : var == OUTPUT_FORCE_AREA ? 1 : var == OUTPUT_FORCE_BENDING ? 2 : var == OUTPUT_FORCE_LINK ? 3 : var == OUTPUT_FORCE_VISC ? 4 : 5;
         static const char *names[6] = {"Volume force", "Area force", "Bending force", "Link force", "Viscous force", "Inner link force"};
         vector<float> o(3 * (size_t)n); for (long i = 0; i < 3 * n; i++) o[(size_t)i] = (float)(comp[(size_t)(slot * 3 * n + i)] * (si ? Parameters::df : 1.0));
         h5_write_2d(file, names[slot], o, n, 3); break; }
-      case OUTPUT_FORCE_REPULSION: h5_write_2d(file, "Repulsion force", vector<float>(3 * (size_t)n, 0.f), n, 3); break;
+      case OUTPUT_FORCE_REPULSION: h5_write_2d(file, "Repulsion force", vec3(rep, si ? Parameters::df : 1.0), n, 3); break;
       case OUTPUT_VERTEX_ID: { vector<float> o((size_t)n); for (long i = 0; i < n; i++) o[(size_t)i] = (float)(i % field.numVertex); h5_write_2d(file, "Vertex Id", o, n, 1); break; }
       case OUTPUT_CELL_ID: { vector<float> o((size_t)n); for (long i = 0; i < n; i++) o[(size_t)i] = (float)ids[(size_t)(first_cell + i / field.numVertex)]; h5_write_2d(file, "Cell Id", o, n, 1); break; }
       case OUTPUT_RES_TIME: h5_write_2d(file, "Res Time", vector<float>((size_t)n, 0.f), n, 1); break;

@@ -187,6 +187,14 @@ def test_reference_pipeflow_driver_passes_its_ci_sanity(tmp_path, gpu):
     if HAVE_HDF5:   # hemocell.writeOutput(): one directory per measurement with fluid and cell files
         out = sorted(os.listdir(str(work / "tmp" / "hdf5")))
         assert len(out) >= 10
+        # particles are written where a block holds them: inside the periodic domain (cells that straddle x = 0 from
+        # the start would otherwise show up at negative x)
+        rbc = str(work / "tmp" / "hdf5" / out[-1] / ("RBC." + out[-1] + ".p.0.h5"))
+        dump = subprocess.run(["/opt/conda/bin/h5dump", "-d", "/Position", "-y", "-w", "0", rbc], capture_output=True, text=True).stdout
+        body = dump[dump.index("DATA {") + 6:dump.rindex("}")]
+        vals = np.array([float(t) for t in body.replace("}", " ").replace(",", " ").split()]).reshape(-1, 3)
+        assert len(vals) == 35 * 642
+        assert vals[:, 0].min() >= -0.5 and vals[:, 0].max() < 102.5
 
 
 def test_reference_stretchcell_driver_passes_its_ci_sanity(tmp_path, gpu):

@@ -207,7 +207,9 @@ __global__ __launch_bounds__(256) void collide_stream_kernel(LatArgs a) {
     collide_guo(f, Fx, Fy, Fz, a.omega);
   }
 #pragma unroll
-  for (int q = 0; q < HC_Q; q++) a.fout[(long)q * a.npad + node] = f[q];
+  // streamed once and read again only after 5 GB of other traffic: non-temporal stores keep the lines out of the way
+  // of the loads (measured: -3 % kernel time on the pipe and on the all-fluid box; non-temporal loads cost 4 %)
+  for (int q = 0; q < HC_Q; q++) __builtin_nontemporal_store(f[q], &a.fout[(long)q * a.npad + node]);
   if (a.ibm && a.dirty_zero[node >> 4] == a.epoch_zero) { a.Fzero[node] = 0.0; a.Fzero[a.npad + node] = 0.0; a.Fzero[2 * a.npad + node] = 0.0; }
 }
 

@@ -723,3 +723,43 @@ def test_full_size_properties_config3(gpu):
     v = cf.velocities
     assert v[:n_rbc * 642, 0].mean() > 0 and v[n_rbc * 642:, 0].mean() > 0
     L.destroy()
+
+
+def test_error_behaviour_of_the_c_abi(gpu):
+    """every entry point returns a status and leaves a message in hc_last_error(); nothing is thrown across the ABI and
+    nothing falls back silently ('Error behaviour')"""
+    lib = gpu.capi.lib()
+    P = gpu.base_parameters()
+
+    def fails(rc, fragment):
+        assert rc != 0
+        msg = lib.hc_last_error().decode()
+        assert fragment in msg, msg
+
+    ptr = C.c_void_p()
+    per = (C.c_int * 3)(1, 0, 0)
+    fails(lib.hcl_create(C.byref(ptr), 1, 8, 8, per, 1.0, 0, 1, 1), "dimension")
+    fails(lib.hcl_create(C.byref(ptr), 8, 8, 8, per, 2.5, 0, 8, 1), "omega")
+    fails(lib.hcl_create(C.byref(ptr), 8, 8, 8, per, 1.0, 4, 8, 2), "slab")
+    L = gpu.Lattice(8, 8, 8, (1, 0, 0), 1.0)
+    fails(lib.hcl_set_mask(L.ptr, None), "null")
+    fails(lib.hcl_collide_stream_part(L.ptr, 7), "part")
+    u = (C.c_double * 3)(0, 0, 0)
+    fails(lib.hcl_set_wall_velocity(L.ptr, 9, u), "class")
+    h = gpu.HemoCell(L, P)
+    T = gpu.CellType.rbc(P)
+    for _ in range(8):
+        h.cellfields.addCellType(T, 1)
+    fails(lib.hcp_add_type(h.cellfields.ptr, T.ptr, 1, None), "8 cell types")
+    c = (C.c_double * 3)(4, 4, 4); a = (C.c_double * 3)(0, 0, 0)
+    fails(lib.hcp_add_cell(h.cellfields.ptr, 11, 0, c, a, 0.0, None), "unknown cell type")
+    fails(lib.hcp_repulsion(h.cellfields.ptr), "hcp_set_repulsion first")
+    fails(lib.hcp_boundary_repulsion(h.cellfields.ptr), "hcp_set_boundary_repulsion first")
+    out = (C.c_double * 3)(); n = C.c_long()
+    fails(lib.hcp_vertex_stats(h.cellfields.ptr, 0, out, C.byref(n)), "what")
+    with pytest.raises(gpu.capi.HcError):
+        gpu.capi.check(lib.hcl_fluid_stats(L.ptr, 5, out, C.byref(n)))
+    # a multi-slab lattice cannot be stepped by the single-domain entry points
+    L2 = gpu.Lattice(8, 8, 8, (1, 0, 0), 1.0, x0=0, nx_global=16, n_slabs=2)
+    fails(lib.hcl_collide_stream(L2.ptr, 1), "multi-slab")
+    L2.destroy(); L.destroy()

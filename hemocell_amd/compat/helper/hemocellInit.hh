@@ -11,9 +11,14 @@ void iniLatticeSquareCouette(plb::MultiBlockLattice3D<U, Descriptor> &lattice, p
   lattice.periodicity().toggle(2, false);
   boundaryCondition.setVelocityConditionOnBlockBoundaries(lattice, top);
   boundaryCondition.setVelocityConditionOnBlockBoundaries(lattice, bottom);
+  // The reference's velocity nodes ARE the wall (z = 0 and z = nz-1, +-vHalf there, helper/hemocellInit.hh:82-84).  This
+  // back end's moving wall (bounce-back + momentum term) acts half a node inside the wall node, so it is given the
+  // velocity the reference's linear profile has at that position: every fluid node then sees the reference's
+  // u(z) = vHalf (1 - 2 z / (nz-1)), i.e. the same shear rate.
   const U vHalf = (nz - 1) * shearRate * 0.5;
-  plb::setBoundaryVelocity(lattice, top, plb::Array<U, 3>(-vHalf, 0.0, 0.0));
-  plb::setBoundaryVelocity(lattice, bottom, plb::Array<U, 3>(vHalf, 0.0, 0.0));
+  const U vWall = vHalf * (U)(nz - 2) / (U)(nz - 1);
+  plb::setBoundaryVelocity(lattice, top, plb::Array<U, 3>(-vWall, 0.0, 0.0));
+  plb::setBoundaryVelocity(lattice, bottom, plb::Array<U, 3>(vWall, 0.0, 0.0));
   plb::setExternalVector(lattice, lattice.getBoundingBox(), Descriptor<U>::ExternalField::forceBeginsAt, plb::Array<U, 3>(0.0, 0.0, 0.0));
   lattice.initialize();
 }

@@ -138,6 +138,14 @@ def test_moving_wall_couette_vs_oracle(orc, gpu):
     z = np.arange(1, nz - 1)
     expect = vhalf - (z - 0.5) * (2 * vhalf) / (nz - 2)      # walls sit half a node outside the first/last fluid node
     assert np.abs(ux - expect).max() < 0.02 * vhalf
+    # the facade's iniLatticeSquareCouette gives the walls vhalf (nz-2)/(nz-1): the fluid then has the profile of the
+    # reference's on-node walls, u(z) = vhalf (1 - 2 z / (nz-1)), i.e. exactly the requested shear rate
+    w = vhalf * (nz - 2) / (nz - 1)
+    Lg.setBoundaryVelocity(3, (w, 0, 0)); Lg.setBoundaryVelocity(4, (-w, 0, 0))
+    Lg.collideAndStream(3000)
+    ux = Lg.rho_u()[1][:, 0].reshape(nx, ny, nz)[0, 0, 1:-1]
+    assert np.abs(ux - vhalf * (1 - 2 * z / (nz - 1))).max() < 2e-3 * vhalf
+    assert abs(np.polyfit(z, ux, 1)[0] + shear) < 2e-3 * shear
     Lo.destroy(); Lg.destroy()
 
 

@@ -362,6 +362,7 @@ def test_one_cell_shear_config_c1(orc, gpu):
     Po = O.make_params(orc, dt=dt); Pg = gpu.base_parameters(dt=dt)
     nz = 20; nx = ny = 2 * nz
     shear = 111.0 * dt; vhalf = (nz - 1) * shear * 0.5     # helper/hemocellInit.hh:82-84
+    vhalf = vhalf * (nz - 2) / (nz - 1)                    # the moving wall acts half a node inside the wall node (compat/helper/hemocellInit.hh)
     mask = np.zeros((nx, ny, nz), np.uint8); mask[:, :, -1] = 3; mask[:, :, 0] = 4
     Lo, Lg = _both_lattices(orc, gpu, nx, ny, nz, (1, 1, 0), 1.0 / Po.tau, mask)
     Lo.set_wall_velocity(0, (-vhalf, 0, 0)); Lo.set_wall_velocity(1, (vhalf, 0, 0))

@@ -93,6 +93,8 @@ SIGNATURES = {
     "hcp_mechanics_components": (C.c_int, [VP, C.c_int, c_double_p]),
     "hc_iterate": (C.c_int, [VP, VP, c_long_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "hcp_cell_extents": (C.c_int, [VP, C.c_int, c_double_p]),
+    "hcp_cell_extents_begin": (C.c_int, [VP, C.c_int]),
+    "hcp_cell_extents_end": (C.c_int, [VP, C.c_int, c_double_p]),
     "hcp_record_doubles": (C.c_size_t, [VP, C.c_int]),
     "hcp_pack_cells": (C.c_int, [VP, C.c_int, c_int_p, C.c_int, C.c_double, VP]),
     "hcp_unpack_cells": (C.c_int, [VP, C.c_int, c_int_p, c_long_p, c_int_p, C.c_int, VP]),

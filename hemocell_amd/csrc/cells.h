@@ -52,6 +52,8 @@ struct hc_cells {
   bool rep_on() const { return rep_enabled || brep_enabled; }
   unsigned int *d_keys[2] = {nullptr, nullptr}; int *d_vals[2] = {nullptr, nullptr}; void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0; long sort_cap = 0;
   int *d_iscratch[2] = {nullptr, nullptr};   // staged slot lists of the envelope exchange (stream ordered, no sync)
+  // asynchronous cell extents (hcp_cell_extents_begin / _end): device block, pinned host block and event per type
+  double *d_ext[8] = {nullptr}, *h_ext[8] = {nullptr}; long ext_cap[8] = {0}, ext_n[8] = {0}; hipEvent_t ext_done[8] = {nullptr}; bool ext_pending[8] = {false};
   // staging of hcp_add_vertex_force (called every iteration by the stretch drivers): pinned host block + device block
   // [n indices | 3n force components], grown on demand; the event guards the pinned block against reuse in flight
   char *h_vf = nullptr, *d_vf = nullptr; size_t vf_cap = 0; hipEvent_t vf_done = nullptr;

@@ -246,6 +246,7 @@ int hcp_destroy(hc_cells *C) {
   if (C->h_ntag) hipHostFree(C->h_ntag);
   if (C->d_ntag) hipFree(C->d_ntag);
   if (C->d_bflag) hipFree(C->d_bflag);
+  for (int t = 0; t < 8; t++) { if (C->d_ext[t]) hipFree(C->d_ext[t]); if (C->h_ext[t]) hipHostFree(C->h_ext[t]); if (C->ext_done[t]) hipEventDestroy(C->ext_done[t]); }
   if (C->h_vf) hipHostFree(C->h_vf);
   if (C->d_vf) hipFree(C->d_vf);
   if (C->vf_done) hipEventDestroy(C->vf_done);

@@ -105,20 +105,48 @@ __global__ __launch_bounds__(256) void owned_count_kernel(long n, const double *
 
 extern "C" {
 
-int hcp_cell_extents(hc_cells *C, int type, double *minmax) {
-  HC_REQUIRE(C && minmax && type >= 0 && type < C->ntypes, "hcp_cell_extents: bad arguments");
+// The kernel and the copy into pinned staging are enqueued and the call returns; _end waits for that copy alone (an
+// event), not for whatever was enqueued on the stream afterwards, so a caller can start the extents early in a step and
+// pick them up later without draining the queue.
+int hcp_cell_extents_begin(hc_cells *C, int type) {
+  HC_REQUIRE(C && type >= 0 && type < C->ntypes, "hcp_cell_extents_begin: bad arguments");
   int rc = sync_to_device(C); if (rc != HC_OK) return rc;
   const long nc = C->ncells[type];
+  C->ext_n[type] = nc; C->ext_pending[type] = true;
   if (nc == 0) return HC_OK;
-  double *d = nullptr;
-  HC_HIP(hipMalloc((void **)&d, (size_t)(3 * nc) * sizeof(double)));
-  hipLaunchKernelGGL(cell_extent_kernel, dim3((unsigned)nc), dim3(256), 0, hc::stream(), C->types[type]->host.nv, (const double *)(C->pos[0] + C->first[type]), d, C->L->x0, C->L->nx);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(minmax, d, (size_t)(3 * nc) * sizeof(double), hipMemcpyDeviceToHost, hc::stream());
-  if (e == hipSuccess) e = hipStreamSynchronize(hc::stream());
-  hipFree(d);
-  if (e != hipSuccess) return hc::hip_fail(e, "hcp_cell_extents", __FILE__, __LINE__);
+  if (nc > C->ext_cap[type]) {
+    if (C->d_ext[type]) HC_HIP(hipFree(C->d_ext[type]));
+    if (C->h_ext[type]) HC_HIP(hipHostFree(C->h_ext[type]));
+    C->d_ext[type] = C->h_ext[type] = nullptr; C->ext_cap[type] = 0;
+    const long cap = nc + nc / 4 + 64;
+    HC_HIP(hipMalloc((void **)&C->d_ext[type], (size_t)(3 * cap) * sizeof(double)));
+    HC_HIP(hipHostMalloc((void **)&C->h_ext[type], (size_t)(3 * cap) * sizeof(double), hipHostMallocDefault));
+    C->ext_cap[type] = cap;
+  }
+  if (!C->ext_done[type]) HC_HIP(hipEventCreateWithFlags(&C->ext_done[type], hipEventDisableTiming));
+  hipLaunchKernelGGL(cell_extent_kernel, dim3((unsigned)nc), dim3(256), 0, hc::stream(), C->types[type]->host.nv,
+                     (const double *)(C->pos[0] + C->first[type]), C->d_ext[type], C->L->x0, C->L->nx);
+  HC_HIP(hipGetLastError());
+  HC_HIP(hipMemcpyAsync(C->h_ext[type], C->d_ext[type], (size_t)(3 * nc) * sizeof(double), hipMemcpyDeviceToHost, hc::stream()));
+  HC_HIP(hipEventRecord(C->ext_done[type], hc::stream()));
   return HC_OK;
+}
+
+int hcp_cell_extents_end(hc_cells *C, int type, double *minmax) {
+  HC_REQUIRE(C && minmax && type >= 0 && type < C->ntypes, "hcp_cell_extents_end: bad arguments");
+  HC_REQUIRE(C->ext_pending[type], "hcp_cell_extents_end: no hcp_cell_extents_begin is pending for this type");
+  HC_REQUIRE(C->ext_n[type] == C->ncells[type], "hcp_cell_extents_end: the cell set changed since hcp_cell_extents_begin");
+  C->ext_pending[type] = false;
+  if (C->ext_n[type] == 0) return HC_OK;
+  HC_HIP(hipEventSynchronize(C->ext_done[type]));
+  std::memcpy(minmax, C->h_ext[type], (size_t)(3 * C->ext_n[type]) * sizeof(double));
+  return HC_OK;
+}
+
+int hcp_cell_extents(hc_cells *C, int type, double *minmax) {
+  HC_REQUIRE(C && minmax && type >= 0 && type < C->ntypes, "hcp_cell_extents: bad arguments");
+  int rc = hcp_cell_extents_begin(C, type); if (rc != HC_OK) return rc;
+  return hcp_cell_extents_end(C, type, minmax);
 }
 
 size_t hcp_record_doubles(const hc_cells *C, int type) {

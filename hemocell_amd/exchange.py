@@ -79,6 +79,7 @@ class HipEngine:
         self.L, self.C, self.device = lattice, cells, device
         self.lib = host.capi.lib()
         self.nx, self.x0, self.nx_global = lattice.nx, lattice.x0, lattice.nx_global
+        self._ext_pending = set()
 
     # ---- fluid
     def halo_buffer(self, width):
@@ -112,10 +113,19 @@ class HipEngine:
         f = sum(self.C.type_range(u)[1] for u in range(t))
         return ids[f:f + self.C.type_range(t)[1]]
 
+    def cell_extents_begin(self, t):
+        """enqueue the extents of type t (stream ordered, returns at once)"""
+        host.check(self.lib.hcp_cell_extents_begin(self.C.ptr, t))
+        self._ext_pending.add(t)
+
     def cell_extents(self, t):
+        """per cell [min x, max x, owned vertices]; waits only for the copy started by cell_extents_begin"""
         n = self.C.type_range(t)[1]
         ext = np.empty((n, 3), dtype=np.float64)
-        host.check(self.lib.hcp_cell_extents(self.C.ptr, t, host.dptr(ext)))
+        if t not in self._ext_pending:
+            host.check(self.lib.hcp_cell_extents_begin(self.C.ptr, t))
+        self._ext_pending.discard(t)
+        host.check(self.lib.hcp_cell_extents_end(self.C.ptr, t, host.dptr(ext)))
         return ext
 
     def pack_cells(self, t, slots, x_shift):
@@ -183,6 +193,7 @@ class SlabProtocol:
         self.halo_fresh = False
         self.overlap = overlap
         self._hb = {}
+        self._hdr = {}
         self.stats = {"cells_sent": 0, "cells_new": 0, "cells_dropped": 0}
 
     # ------------------------------------------------------------------ fluid halos
@@ -208,6 +219,23 @@ class SlabProtocol:
         return finish
 
     # ------------------------------------------------------------------ particle envelopes
+    def plan_cells(self):
+        """start the per-cell extents of every type; called at the start of a step that ends with sync_cells, when the
+        positions are already those the sync will see (they change only in advance), so that the copy is long done
+        when it is needed and the host never drains the stream for it"""
+        for t in range(self.e.n_types()):
+            self.e.cell_extents_begin(t)
+
+    def _header_buffers(self, t):
+        """fixed-size id headers of type t: [host staging, device send, device receive] per side, made once"""
+        if t not in self._hdr:
+            dev = self._dev()
+            pin = dev != "cpu"
+            self._hdr[t] = [(torch.zeros(MAX_SHARED, dtype=torch.int64, pin_memory=pin),
+                             torch.zeros(MAX_SHARED, dtype=torch.int64, device=dev),
+                             torch.zeros(MAX_SHARED, dtype=torch.int64, device=dev)) for _ in (0, 1)]
+        return self._hdr[t]
+
     def sync_cells(self):
         e, comm = self.e, self.comm
         x0, x1 = e.x0, e.x0 + e.nx
@@ -229,15 +257,16 @@ class SlabProtocol:
                 send[side] = (slots, ids[slots])
             # phase 1: one fixed-size header per side: [count, id_0 .. id_{count-1}, padding]
             assert max(len(send[0][0]), len(send[1][0])) < MAX_SHARED, "more cells cross one slab face than the header holds"
-            hdr_s, hdr_r = [], []
+            hdr = self._header_buffers(t)
             for side in (0, 1):
-                hh = np.zeros(MAX_SHARED, dtype=np.int64)
-                hh[0] = len(send[side][0]); hh[1:1 + len(send[side][0])] = send[side][1]
-                hdr_s.append(torch.from_numpy(hh).to(self._dev()))
-                hdr_r.append(torch.zeros(MAX_SHARED, dtype=torch.int64, device=self._dev()))
-            comm.exchange(hdr_s[0], hdr_s[1], hdr_r[0], hdr_r[1])()
-            hr = [hdr_r[0].cpu().numpy() if comm.lo is not None else np.zeros(1, np.int64),
-                  hdr_r[1].cpu().numpy() if comm.hi is not None else np.zeros(1, np.int64)]
+                stage, dev_s, _ = hdr[side]
+                k = len(send[side][0])
+                hh = stage.numpy()
+                hh[0] = k; hh[1:1 + k] = send[side][1]
+                dev_s[:1 + k].copy_(stage[:1 + k], non_blocking=True)
+            comm.exchange(hdr[0][1], hdr[1][1], hdr[0][2], hdr[1][2])()
+            hr = [hdr[0][2].cpu().numpy() if comm.lo is not None else np.zeros(1, np.int64),
+                  hdr[1][2].cpu().numpy() if comm.hi is not None else np.zeros(1, np.int64)]
             n_lo, n_hi = int(hr[0][0]), int(hr[1][0])
             ids_r = [hr[0][1:1 + n_lo], hr[1][1:1 + n_hi]]
             # phase 2: records
@@ -247,26 +276,30 @@ class SlabProtocol:
             rec_r = [e.record_buffer(t, n_lo), e.record_buffer(t, n_hi)]
             comm.exchange(rec_s[0], rec_s[1], rec_r[0], rec_r[1])()
             self.stats["cells_sent"] += len(send[0][0]) + len(send[1][0])
-            # phase 3: merge
-            slot_of = {int(i): k for k, i in enumerate(ids)}
+            # phase 3: merge.  Incoming ids are looked up in the local ids (sorted search); unknown ones are appended
+            # in arrival order, and a cell that arrives from both sides (world == 2) is new only the first time
             refreshed = np.zeros(n, dtype=bool)
-            n_now = n
+            known_ids, known_slots = ids, np.arange(n, dtype=np.int64)
             for side, cnt in ((0, n_lo), (1, n_hi)):
                 if cnt == 0:
                     continue
                 rid = np.ascontiguousarray(ids_r[side])
-                slots = np.empty(cnt, np.int32); is_new = np.zeros(cnt, np.int32)
-                for k, cid in enumerate(rid):
-                    s = slot_of.get(int(cid))
-                    if s is None:
-                        s = n_now; n_now += 1
-                        slot_of[int(cid)] = s
-                        is_new[k] = 1
-                        self.stats["cells_new"] += 1
-                    elif s < n:
-                        refreshed[s] = True
-                    slots[k] = s
-                e.unpack_cells(t, slots, rid, is_new, rec_r[side])
+                order = np.argsort(known_ids, kind="stable")
+                pos = np.searchsorted(known_ids[order], rid)
+                pos_c = np.minimum(pos, len(known_ids) - 1) if len(known_ids) else np.zeros(cnt, np.int64)
+                hit = (known_ids[order][pos_c] == rid) if len(known_ids) else np.zeros(cnt, bool)
+                slots = np.empty(cnt, np.int64)
+                slots[hit] = known_slots[order][pos_c[hit]]
+                n_new = int((~hit).sum())
+                first_new = len(known_ids)
+                slots[~hit] = first_new + np.arange(n_new)
+                is_new = (~hit).astype(np.int32)
+                refreshed[slots[hit & (slots < n)]] = True
+                self.stats["cells_new"] += n_new
+                if n_new:
+                    known_ids = np.concatenate([known_ids, rid[~hit]])
+                    known_slots = np.concatenate([known_slots, first_new + np.arange(n_new)])
+                e.unpack_cells(t, slots.astype(np.int32), rid, is_new, rec_r[side])
             # phase 4: a copy without any local vertex survives only while its owner keeps refreshing it
             # (deleteNonLocalParticles, core/hemoCellFields.cpp:676-688)
             drop = np.nonzero((ext[:, 2] == 0) & ~refreshed)[0].astype(np.int32)
@@ -285,6 +318,8 @@ class SlabProtocol:
     def step(self):
         e = self.e
         it = self.iter
+        if it % self.k_p == 0:
+            self.plan_cells()                                 # extents for the envelope sync at the end of this step
         e.repulsion(it)                                       # core/hemoCell.cpp:307-312
         e.spread()                                            # :313
         if self.halo_fresh:

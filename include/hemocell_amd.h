@@ -199,6 +199,11 @@ int hc_iterate(hc_lattice *L, hc_cells *C, long *iter, int n, int particle_times
  * A record is 9 doubles per vertex: position, velocity, force (the mutable part of serializeValues_t,
  * core/hemoCellParticle.h:45-63); x_shift is the periodic offset (+-nx_global) of :33-65. */
 int hcp_cell_extents(hc_cells *C, int type, double *ext /*[n_cells][3] = min x, max x, #vertices whose nearest node is in this slab*/);
+/* asynchronous form: _begin enqueues the kernel and the copy into pinned staging and returns; _end waits for that copy
+ * only (an event), not for work enqueued afterwards, so the extents can be started early in a step and picked up
+ * without draining the stream.  The cell set must not change in between. */
+int hcp_cell_extents_begin(hc_cells *C, int type);
+int hcp_cell_extents_end(hc_cells *C, int type, double *ext);
 size_t hcp_record_doubles(const hc_cells *C, int type); /* doubles per cell record */
 int hcp_pack_cells(hc_cells *C, int type, const int *slots, int n, double x_shift, double *dev_buf);
 /* merge rule of HemoCellParticleField::addParticle (core/hemoCellParticleField.cpp:173-235): a local vertex

@@ -110,6 +110,9 @@ class FakeEngine:
     def repulsion(self, it):
         pass
 
+    def cell_extents_begin(self, t):
+        pass
+
     def spread(self):
         pass
 

@@ -2,8 +2,11 @@
 
 protocol overhead on one GPU: the slab protocol with a loopback transport (the slab is its own periodic
 neighbour; cells are kept away from the seam so that no record crosses) against hc_iterate on the same case"""
-import sys, time, types
-sys.path.insert(0, '.')
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from hemocell_amd import host
 from hemocell_amd.packing import pack_pipe_rbc
@@ -56,7 +59,3 @@ proto.k_p = 10**9
 t_nop = timeit(lambda k: proto.run(k))
 print("hc_iterate: %.4f (k_p=5)  %.4f (no particle update)" % (t_iter, t_iter_nop))
 print("protocol  : %.4f (k_p=5)  %.4f (k_p=5, sync_cells skipped)  %.4f (no particle update)" % (t_full, t_nosync, t_nop), flush=True)
-import cProfile, pstats
-proto.k_p = 5
-pr = cProfile.Profile(); pr.enable(); proto.run(100); torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(28)

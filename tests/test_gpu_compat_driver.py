@@ -224,3 +224,25 @@ def test_reference_stretchcell_driver_passes_its_ci_sanity(tmp_path, gpu):
     assert all(81.12 < v < 81.19 for v in um3[1:]), um3
     surf = [float(_cut(l, (":", 2), (" ", 2))) for l in log if "Surface:" in l]
     assert len(surf) == 11 and all(129.34 < s < 133.04 for s in surf[1:]), surf
+
+
+def test_reference_onecellshear_driver_runs_config_c1(tmp_path, gpu):
+    """BASELINE config 1 through the reference's own driver and config (examples/oneCellShear: 40 x 40 x 20 box, shear
+    rate 111 1/s, one RBC, 100 000 iterations, report every 2000).  The reference holds no known-answer for this case,
+    so the checks are physical: the membrane keeps its volume and area, the cell stays between the walls, it is
+    stretched by the shear (positive deformation index that settles), and the run reaches the end."""
+    import shutil
+    work = tmp_path / "shear_case"
+    shutil.copytree(os.path.join(ROOT, "tests", "golden", "shear_case"), str(work))
+    r = subprocess.run([_ref_driver("oneCellShear"), "config.xml"], cwd=str(work), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "Simulation finished" in r.stdout
+    rows = np.array([[float(x) for x in l.split()] for l in open(str(work / "stretch.log")).read().splitlines()])
+    assert rows.shape == (50, 8) and rows[-1, 0] == 100000
+    vol, surf, diam, di = rows[:, 4], rows[:, 5], rows[:, 6], rows[:, 7]
+    assert np.abs(vol - 100).max() < 0.5 and np.abs(surf - 100).max() < 2.0
+    assert (di > 0).all() and di.max() < 20 and abs(di[-1] - di[-10:].mean()) < 1.0      # deformed and settled
+    assert diam.min() > 7.5 and diam.max() < 9.5
+    centre = [l for l in r.stdout.splitlines() if "Cell center at" in l][-1]
+    z = float(centre.split("{")[1].split("}")[0].split(",")[2])
+    assert 3.0 < z < 7.0                                                                # stays between the walls (box height 10 um)

@@ -45,3 +45,17 @@ def test_product_never_imports_oracle():
                 assert "libhemo_oracle" not in txt, f
                 assert not re.search(r"^\s*(from\s+oracle|import\s+oracle)", txt, flags=re.M), f
                 assert not re.search(r"#include\s*[<\"][^>\"]*oracle", txt), f
+
+
+def test_header_is_plain_c_and_a_c_client_links(tmp_path):
+    """the boundary is a C ABI: include/hemocell_amd.h must compile as strict C99 and a C program must link against the
+    library with nothing but that header (tests/cabi/c_abi_smoke.c; it is run on the GPU by tests/test_gpu_parity.py)"""
+    import subprocess
+    from hemocell_amd import capi
+    capi.lib()
+    libdir = os.path.dirname(capi.LIB_PATH)
+    out = str(tmp_path / "c_abi_smoke")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "cabi", "c_abi_smoke.c"), "-o", out, "-L" + libdir, "-lhemocell_amd", "-lm",
+                        "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]

@@ -764,3 +764,33 @@ def test_error_behaviour_of_the_c_abi(gpu):
     L2 = gpu.Lattice(8, 8, 8, (1, 0, 0), 1.0, x0=0, nx_global=16, n_slabs=2)
     fails(lib.hcl_collide_stream(L2.ptr, 1), "multi-slab")
     L2.destroy(); L.destroy()
+
+
+def test_plain_c_client_of_the_abi(tmp_path, gpu):
+    """tests/cabi/c_abi_smoke.c: a C99 program that knows only include/hemocell_amd.h drives one RBC through 50 iterations;
+    its numbers equal those of the Python host on the same case"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(gpu.capi.LIB_PATH)
+    exe = str(tmp_path / "c_abi_smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cabi", "c_abi_smoke.c"),
+                           "-o", exe, "-L" + libdir, "-lhemocell_amd", "-lm", "-Wl,-rpath," + libdir])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = dict((l.split()[0], l.split()[1:]) for l in r.stdout.splitlines())
+    assert out["ITER"] == ["50"] and out["CELLS"][:1] == ["1"] and out["CELLS"][2] == "642"
+    nx, ny, nz = 32, 26, 26
+    P = gpu.base_parameters()
+    mask, R = gpu.pipe_mask(nx, ny, nz)
+    L = gpu.Lattice(nx, ny, nz, (1, 0, 0), 1.0 / P.tau); L.defineBounceBack(mask); L.latticeEquilibrium(); L.setExternalVector((2e-6, 0, 0))
+    h = gpu.HemoCell(L, P); h.cellfields.addCellType(gpu.CellType.rbc(P), 1)
+    assert h.cellfields.addCell(0, (16.0, 12.5, 12.5), (90, 0, 0))
+    h.cellfields.applyConstitutiveModel(0, True); h.iterate(50)
+    stats = out["VMAX"]
+    vmax, umax, vol = float(stats[0]), float(stats[2]), float(stats[4])
+    cen = np.array([float(x) for x in stats[6:9]])
+    info = h.cellfields.cell_info(0)
+    assert abs(vmax - h.cellfields.vertex_stats(1)[1]) <= 1e-6 * vmax and abs(umax - L.fluid_stats(0)[1]) <= 1e-6 * umax   # printed with 7 digits
+    assert abs(vol - info["volume"][0]) <= 1e-6 and np.abs(cen - info["centroid"][0]).max() <= 1e-6
+    L.destroy()

@@ -792,5 +792,5 @@ def test_plain_c_client_of_the_abi(tmp_path, gpu):
     cen = np.array([float(x) for x in stats[6:9]])
     info = h.cellfields.cell_info(0)
     assert abs(vmax - h.cellfields.vertex_stats(1)[1]) <= 1e-6 * vmax and abs(umax - L.fluid_stats(0)[1]) <= 1e-6 * umax   # printed with 7 digits
-    assert abs(vol - info["volume"][0]) <= 1e-6 and np.abs(cen - info["centroid"][0]).max() <= 1e-6
+    assert abs(vol - info["volume"][0]) <= 1e-6 and np.abs(cen - info["position"][0]).max() <= 1e-6
     L.destroy()

@@ -78,6 +78,36 @@ class SlabRunner:
         else:
             self.exchange.run(n)
 
+    # ---- diagnostics across slabs: the reference gathers per-block statistics (HemoCellGatheringFunctional,
+    # core/hemoCellFunctional.h:101-112); here a few scalars are all-reduced at output cadence
+    def _reduce(self, mn, mx, total, count):
+        if self.world == 1:
+            return mn, mx, total, count
+        import torch
+        import torch.distributed as dist
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        big = 1e300
+        lo = torch.tensor([mn if count else big], dtype=torch.float64, device=dev)
+        hi = torch.tensor([mx if count else -big], dtype=torch.float64, device=dev)
+        sm = torch.tensor([total, float(count)], dtype=torch.float64, device=dev)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        n = int(sm[1].item())
+        return (float(lo.item()) if n else 0.0), (float(hi.item()) if n else 0.0), float(sm[0].item()), n
+
+    def fluid_stats(self, what=0):
+        """FluidInfo statistics over the whole domain: (min, max, mean, nodes)"""
+        if self.exchange is not None and what == 0:
+            self.exchange.protocol.halo_exchange_begin(1)()      # velocities on the face planes pull from the halo planes
+        mn, mx, avg, n = self.lattice.fluid_stats(what)
+        mn, mx, total, n = self._reduce(mn, mx, avg * n, n)
+        return mn, mx, (total / n if n else 0.0), n
+
+    def vertex_stats(self, what=2):
+        """ParticleInfo statistics over all owned vertices of all slabs: (min, max, mean, vertices)"""
+        mn, mx, avg, n = self.cells.vertex_stats(what) if not self.fluid_only else (0.0, 0.0, 0.0, 0)
+        mn, mx, total, n = self._reduce(mn, mx, avg * n, n)
+        return mn, mx, (total / n if n else 0.0), n
+
     # ---- inspection helpers (tests / output): gather-free, per rank
     def populations(self):
         """post-stream populations of this slab; the view pulls from the halo planes, so refresh them first"""

@@ -61,8 +61,9 @@ def _worker(rank, world, port, out, rep=False):
     r.run(STEPS)
     cid, vid, pos = r.owned_vertex_table(0)
     pcid, pvid, ppos = r.owned_vertex_table(1)
+    gstats = (r.fluid_stats(0), r.vertex_stats(1), r.vertex_stats(2))    # all-reduced: every rank gets the global numbers
     torch.save(dict(f=r.populations(), cid=cid, vid=vid, pos=pos, pcid=pcid, pvid=pvid, ppos=ppos, held=r.cells.counts()[1],
-                    stats=r.exchange.protocol.stats),
+                    stats=r.exchange.protocol.stats, gstats=gstats),
                os.path.join(out, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -108,5 +109,11 @@ def test_slabs_match_single_domain(tmp_path, gpu, world, rep):
     assert n_new + n_drop > 0                      # envelope copies changed hands during the run
     if world == 2:
         assert n_new > 0 and n_drop > 0            # both a fresh copy and a dropped copy (faces at x = 72 and the seam)
+    # diagnostics all-reduced over the slabs equal those of the single domain (same values on every rank)
+    ref_stats = (ref.fluid_stats(0), ref.vertex_stats(1), ref.vertex_stats(2))
+    for r in res:
+        for got, want in zip(r["gstats"], ref_stats):
+            assert got[3] == want[3]                                          # same number of nodes / owned vertices
+            assert np.allclose(got[:3], want[:3], rtol=1e-6, atol=1e-18), (got, want)
     travelled = np.abs(allpos[:, 0] - _initial_x()).max()
     assert travelled > 5.0, travelled

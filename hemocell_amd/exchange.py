@@ -256,7 +256,9 @@ class SlabProtocol:
                 slots = slots[order]
                 send[side] = (slots, ids[slots])
             # phase 1: one fixed-size header per side: [count, id_0 .. id_{count-1}, padding]
-            assert max(len(send[0][0]), len(send[1][0])) < MAX_SHARED, "more cells cross one slab face than the header holds"
+            if max(len(send[0][0]), len(send[1][0])) >= MAX_SHARED:
+                raise host.capi.HcError("more cells cross one slab face (%d) than the id header holds (%d)"
+                                        % (max(len(send[0][0]), len(send[1][0])), MAX_SHARED - 1))
             hdr = self._header_buffers(t)
             for side in (0, 1):
                 stage, dev_s, _ = hdr[side]
@@ -364,7 +366,8 @@ class SlabExchange:
         self.engine = HipEngine(runner.lattice, runner.cells, dev)
         self.comm = comm or NeighbourComm(runner.rank, runner.world, runner.periodic[0])
         self.protocol = SlabProtocol(self.engine, self.comm, runner.k_p, runner.nx_global, runner.periodic[0])
-        assert runner.nx >= 40, "a slab must be wider than two cell diameters plus the envelope"
+        if runner.nx < 40:
+            raise host.capi.HcError("a slab must be at least 40 planes wide (two cell diameters plus the envelope), got %d" % runner.nx)
 
     def load_cells(self, t, centres, angles, min_dist_um=0.0, radius=9.0):
         """place every cell whose extent touches this slab's extended region; periodic images across the

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import Material, Params, check, dptr, lptr
+from .capi import HcError, Material, Params, check, dptr, lptr
 
 HALO = 2
 
@@ -69,7 +69,8 @@ class Lattice:
         """mask_global: uint8 [nx_global][ny][nz] (1 = BounceBack).  The slab's halo planes are filled
         from the global array (periodic wrap in x if enabled, otherwise wall)."""
         m = np.ascontiguousarray(mask_global, dtype=np.uint8)
-        assert m.shape == (self.nx_global, self.ny, self.nz), m.shape
+        if m.shape != (self.nx_global, self.ny, self.nz):
+            raise HcError("mask must have the global shape %s, got %s" % ((self.nx_global, self.ny, self.nz), m.shape))
         xs = np.arange(self.x0 - HALO, self.x0 + self.nx + HALO)
         if self.periodic[0]:
             local = m[np.mod(xs, self.nx_global)]
@@ -117,7 +118,8 @@ class Lattice:
 
     def set_populations(self, f):
         f = np.ascontiguousarray(f, dtype=np.float64)
-        assert f.shape == (self.n, 19)
+        if f.shape != (self.n, 19):
+            raise HcError("populations must have shape (%d, 19), got %s" % (self.n, f.shape))
         check(self.lib.hcl_upload_populations(self.ptr, dptr(f)))
 
     def rho_u(self):
@@ -258,7 +260,8 @@ class Cells:
 
     def _set(self, what, a):
         a = np.ascontiguousarray(a, dtype=np.float64)
-        assert a.shape == (self.counts()[0], 3)
+        if a.shape != (self.counts()[0], 3):
+            raise HcError("vertex array must have shape (%d, 3), got %s" % (self.counts()[0], a.shape))
         check(self.lib.hcp_upload(self.ptr, what, dptr(a)))
 
     positions = property(lambda s: s._get(0), lambda s, a: s._set(0, a))

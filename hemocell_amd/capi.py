@@ -78,6 +78,8 @@ SIGNATURES = {
     "hcp_download": (C.c_int, [VP, C.c_int, c_double_p]),
     "hcp_upload": (C.c_int, [VP, C.c_int, c_double_p]),
     "hcp_download_cell_ids": (C.c_int, [VP, c_long_p]),
+    "hcp_download_records": (C.c_int, [VP, C.c_void_p, C.c_long]),
+    "hcp_upload_records": (C.c_int, [VP, C.c_void_p, C.c_long]),
     "hcp_add_vertex_force": (C.c_int, [VP, c_long_p, C.c_int, c_double_p]),
     "hcp_set_repulsion": (C.c_int, [VP, C.c_double, C.c_double, C.c_int]),
     "hcp_repulsion": (C.c_int, [VP]),

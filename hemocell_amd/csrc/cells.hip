@@ -6,6 +6,8 @@
 //   core/hemoCellParticle.h:188-203, core/hemoCellParticleField.cpp:566-588   advance
 //   core/hemoCell.cpp:299-376                                                 iterate
 #include "cells.h"
+#include <cstddef>
+#include <utility>
 
 namespace {
 
@@ -372,6 +374,90 @@ int hcp_upload(hc_cells *C, int what, const double *in) {
     o += dst.size();
   }
   C->host_dirty = true;
+  return HC_OK;
+}
+
+// ---- the reference's particle record, HemoCellParticle::serializeValues_t (core/hemoCellParticle.h:45-63): 120 bytes,
+// v @0, position @24, force @48, force_repulsion @72 (3 doubles each), plint cellId @96, uint16 vertexId @104,
+// uint restime @108, uchar celltype @112.  A binding that keeps libhemocell's std::vector<HemoCellParticle> can hand
+// its records over and get them back in this layout.
+namespace {
+struct SvRecord {
+  double v[3], position[3], force[3], force_repulsion[3];
+  long cellId; unsigned short vertexId; unsigned int restime; unsigned char celltype;
+};
+static_assert(sizeof(SvRecord) == 120, "serializeValues_t is 120 bytes");
+static_assert(offsetof(SvRecord, cellId) == 96 && offsetof(SvRecord, vertexId) == 104 && offsetof(SvRecord, restime) == 108 &&
+              offsetof(SvRecord, celltype) == 112, "serializeValues_t field offsets");
+}  // namespace
+
+int hcp_download_records(hc_cells *C, void *records, long n_records) {
+  HC_REQUIRE(C && records && n_records >= 0, "hcp_download_records: bad arguments");
+  int rc = sync_to_host(C); if (rc != HC_OK) return rc;
+  long total = 0;
+  for (int t = 0; t < C->ntypes; t++) total += (long)C->hids[t].size() * C->types[t]->host.nv;
+  HC_REQUIRE(n_records == total, "hcp_download_records: the buffer must hold exactly one record per vertex (hcp_counts)");
+  std::vector<double> rep((size_t)(3 * total), 0.0);
+  if (C->rep[0] && total) { rc = hcp_download_repulsion(C, rep.data()); if (rc != HC_OK) return rc; }
+  SvRecord *out = static_cast<SvRecord *>(records);
+  long o = 0;
+  for (int t = 0; t < C->ntypes; t++) {
+    const int nv = C->types[t]->host.nv;
+    for (size_t c = 0; c < C->hids[t].size(); c++)
+      for (int i = 0; i < nv; i++, o++) {
+        SvRecord &r = out[o];
+        std::memset(&r, 0, sizeof(r));
+        const size_t k = 3 * (c * (size_t)nv + (size_t)i);
+        for (int d = 0; d < 3; d++) { r.v[d] = C->hvel[t][k + d]; r.position[d] = C->hpos[t][k + d]; r.force[d] = C->hfrc[t][k + d]; r.force_repulsion[d] = rep[(size_t)(3 * o + d)]; }
+        r.cellId = C->hids[t][c]; r.vertexId = (unsigned short)i; r.restime = 0; r.celltype = (unsigned char)t;
+      }
+  }
+  return HC_OK;
+}
+
+// Replaces the whole vertex population by the given records (any order).  Every cell must be complete -- one record
+// per vertexId of its type -- as the reference requires before mechanics (deleteIncompleteCells); cells keep the order
+// of their first record within their type.
+int hcp_upload_records(hc_cells *C, const void *records, long n_records) {
+  HC_REQUIRE(C && (records || n_records == 0) && n_records >= 0, "hcp_upload_records: bad arguments");
+  int rc = sync_to_host(C); if (rc != HC_OK) return rc;
+  const SvRecord *in = static_cast<const SvRecord *>(records);
+  std::vector<long> ids[8]; std::vector<double> pos[8], vel[8], frc[8], rep[8]; std::vector<int> seen[8];
+  std::vector<std::pair<long, long>> index[8];   // (cellId, slot), sorted on demand
+  for (long k = 0; k < n_records; k++) {
+    const SvRecord &r = in[k];
+    const int t = r.celltype;
+    HC_REQUIRE(t < C->ntypes, "hcp_upload_records: record with an unknown celltype");
+    const int nv = C->types[t]->host.nv;
+    HC_REQUIRE(r.vertexId < nv, "hcp_upload_records: vertexId out of range for its cell type");
+    long slot = -1;
+    for (size_t c = ids[t].size(); c-- > 0;) if (ids[t][c] == r.cellId) { slot = (long)c; break; }   // records of a cell usually arrive together
+    if (slot < 0) {
+      slot = (long)ids[t].size(); ids[t].push_back(r.cellId);
+      pos[t].resize(pos[t].size() + 3 * (size_t)nv, 0.0); vel[t].resize(pos[t].size(), 0.0); frc[t].resize(pos[t].size(), 0.0); rep[t].resize(pos[t].size(), 0.0);
+      seen[t].resize(seen[t].size() + (size_t)nv, 0);
+    }
+    const size_t v = (size_t)slot * nv + r.vertexId;
+    HC_REQUIRE(!seen[t][v], "hcp_upload_records: duplicate (cellId, vertexId)");
+    seen[t][v] = 1;
+    for (int d = 0; d < 3; d++) { pos[t][3 * v + d] = r.position[d]; vel[t][3 * v + d] = r.v[d]; frc[t][3 * v + d] = r.force[d]; rep[t][3 * v + d] = r.force_repulsion[d]; }
+  }
+  for (int t = 0; t < C->ntypes; t++) for (int s : seen[t]) HC_REQUIRE(s, "hcp_upload_records: incomplete cell (a vertexId is missing)");
+  for (int t = 0; t < C->ntypes; t++) { C->hids[t].swap(ids[t]); C->hpos[t].swap(pos[t]); C->hvel[t].swap(vel[t]); C->hfrc[t].swap(frc[t]); }
+  C->host_dirty = true;
+  rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  if (C->rep[0]) {   // force_repulsion lives on the device only
+    std::vector<double> tmp;
+    for (int t = 0; t < C->ntypes; t++) {
+      const size_t n = rep[t].size() / 3;
+      if (!n) continue;
+      tmp.resize(n);
+      for (int d = 0; d < 3; d++) {
+        for (size_t i = 0; i < n; i++) tmp[i] = rep[t][3 * i + d];
+        HC_HIP(hipMemcpy(C->rep[d] + C->first[t], tmp.data(), n * sizeof(double), hipMemcpyHostToDevice));
+      }
+    }
+  }
   return HC_OK;
 }
 

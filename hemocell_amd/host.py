@@ -273,6 +273,22 @@ class Cells:
         check(self.lib.hcp_download_cell_ids(self.ptr, lptr(ids)))
         return ids
 
+    # HemoCellParticle::serializeValues_t (core/hemoCellParticle.h:45-63), 120 bytes per vertex
+    SV_DTYPE = np.dtype({"names": ["v", "position", "force", "force_repulsion", "cellId", "vertexId", "restime", "celltype"],
+                         "formats": [("<f8", 3), ("<f8", 3), ("<f8", 3), ("<f8", 3), "<i8", "<u2", "<u4", "u1"],
+                         "offsets": [0, 24, 48, 72, 96, 104, 108, 112], "itemsize": 120})
+
+    def records(self):
+        """every vertex as the reference's particle record"""
+        rec = np.zeros(self.counts()[0], dtype=self.SV_DTYPE)
+        check(self.lib.hcp_download_records(self.ptr, rec.ctypes.data, len(rec)))
+        return rec
+
+    def set_records(self, rec):
+        """replace the whole population by these records (any order, complete cells)"""
+        rec = np.ascontiguousarray(rec, dtype=self.SV_DTYPE)
+        check(self.lib.hcp_upload_records(self.ptr, rec.ctypes.data, len(rec)))
+
     def addVertexForce(self, vertex_index, f):
         idx = np.ascontiguousarray(vertex_index, dtype=np.int64)
         ff = np.ascontiguousarray(f, dtype=np.float64).reshape(len(idx), 3)

@@ -158,6 +158,13 @@ int hcp_type_range(const hc_cells *C, int type, long *first_vertex, long *n_cell
 int hcp_download(hc_cells *C, int what, double *out);
 int hcp_upload(hc_cells *C, int what, const double *in);
 int hcp_download_cell_ids(hc_cells *C, long *ids);
+/* The same state in the reference's own particle record, HemoCellParticle::serializeValues_t (core/hemoCellParticle.h:45-63,
+ * 120 bytes: v @0, position @24, force @48, force_repulsion @72, plint cellId @96, uint16 vertexId @104, uint restime @108,
+ * uchar celltype @112), so that a binding can hand over the contents of libhemocell's std::vector<HemoCellParticle>:
+ * download writes one record per vertex (n_records = hcp_counts vertices; types, cells, vertices in order);
+ * upload replaces the whole population by the given records, in any order, every cell complete. */
+int hcp_download_records(hc_cells *C, void *records, long n_records);
+int hcp_upload_records(hc_cells *C, const void *records, long n_records);
 /* HemoCellStretch::ForceForcedLsps (helper/hemoCellStretch.cpp:63-78): sv.force += f on listed vertices */
 int hcp_add_vertex_force(hc_cells *C, const long *vertex_index, int n, const double *f /*[n][3]*/);
 /* hemocell.setRepulsion(k, cutoff) + setRepulsionTimeScaleSeperation (core/hemoCell.cpp:394-397,420-426); the

@@ -794,3 +794,41 @@ def test_plain_c_client_of_the_abi(tmp_path, gpu):
     assert abs(vmax - h.cellfields.vertex_stats(1)[1]) <= 1e-6 * vmax and abs(umax - L.fluid_stats(0)[1]) <= 1e-6 * umax   # printed with 7 digits
     assert abs(vol - info["volume"][0]) <= 1e-6 and np.abs(cen - info["position"][0]).max() <= 1e-6
     L.destroy()
+
+
+def test_particle_records_in_the_reference_layout(gpu):
+    """row a11: HemoCellParticle::serializeValues_t is 120 bytes with v @0, position @24, force @48, force_repulsion @72,
+    cellId @96, vertexId @104, restime @108, celltype @112 (core/hemoCellParticle.h:45-63).  The library hands the
+    vertices over in that layout and takes them back in any order."""
+    P = gpu.base_parameters()
+    nx, ny, nz = 48, 34, 34
+    mask, R = gpu.pipe_mask(nx, ny, nz)
+    L = gpu.Lattice(nx, ny, nz, (1, 0, 0), 1.0 / P.tau); L.defineBounceBack(mask); L.latticeEquilibrium(); L.setExternalVector((3e-5, 0, 0))
+    h = gpu.HemoCell(L, P); cf = h.cellfields
+    cf.addCellType(gpu.CellType.rbc(P), 1); cf.addCellType(gpu.CellType.plt(P), 1)
+    assert cf.addCell(0, (14.0, 16.5, 15.2), (90, 0, 0), cell_id=7) and cf.addCell(0, (33.0, 17.0, 17.5), (70, 10, 0), cell_id=3)
+    assert cf.addCell(1, (24.0, 16.5, 9.0), (0, 0, 0), cell_id=11)
+    cf.setRepulsion(2e-6, 0.7, 1); cf.applyConstitutiveModel(0, True); h.iterate(10)
+    assert cf.SV_DTYPE.itemsize == 120
+    rec = cf.records()
+    assert len(rec) == 2 * 642 + 66
+    assert np.array_equal(rec["position"], cf.positions) and np.array_equal(rec["v"], cf.velocities)
+    assert np.array_equal(rec["force"], cf.forces) and np.array_equal(rec["force_repulsion"], cf.repulsion_forces)
+    assert list(rec["cellId"][[0, 642, 1284]]) == [7, 3, 11] and list(rec["celltype"][[0, 642, 1284]]) == [0, 0, 1]
+    assert np.array_equal(rec["vertexId"][:642], np.arange(642)) and np.array_equal(rec["vertexId"][1284:], np.arange(66))
+    # hand the records back shuffled, with the platelet moved: same state, the moved cell moved
+    rng = np.random.default_rng(1)
+    back = rec.copy()
+    back["position"][1284:, 0] += 2.0
+    cf.set_records(back[rng.permutation(len(back))])
+    again = cf.records()
+    key = lambda r: np.lexsort((r["vertexId"], r["cellId"], r["celltype"]))
+    a, b = again[key(again)], back[key(back)]
+    for name in cf.SV_DTYPE.names:
+        assert np.array_equal(a[name], b[name]), name
+    # an incomplete cell is refused, as the reference would delete it before any mechanics
+    with pytest.raises(gpu.capi.HcError, match="incomplete"):
+        cf.set_records(back[:-1])
+    h.iterate(5)
+    assert np.isfinite(cf.positions).all()
+    L.destroy()

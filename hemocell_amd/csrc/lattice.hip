@@ -575,13 +575,16 @@ int hcl_set_body_force(hc_lattice *L, const double F[3]) {
 
 int hcl_collide_stream_part(hc_lattice *L, int part) {
   HC_REQUIRE(L, "hcl_collide_stream_part: null lattice");
-  HC_REQUIRE(part >= 0 && part <= 2, "hcl_collide_stream_part: part must be 0, 1 or 2");
+  HC_REQUIRE(part >= 0 && part <= 4, "hcl_collide_stream_part: part must be 0..4");
+  HC_REQUIRE(part < 3 || L->nx >= 4, "hcl_collide_stream_part: parts 3 and 4 need a slab of at least 4 planes");
   hc::ProfScope prof(hc::PK_COLLIDE);
   int rc = HC_OK;
   if (part == 0) rc = launch_collide(L, 0, L->nx);
   else if (part == 1) rc = launch_collide(L, 1, L->nx - 2);
-  else { rc = launch_collide(L, 0, 1); if (rc == HC_OK) rc = launch_collide(L, L->nx - 1, 1); }
-  if (rc == HC_OK && L->n_slabs > 1 && part != 1 && L->ibm) {
+  else if (part == 2) { rc = launch_collide(L, 0, 1); if (rc == HC_OK) rc = launch_collide(L, L->nx - 1, 1); }
+  else if (part == 3) rc = launch_collide(L, 2, L->nx - 4);
+  else { rc = launch_collide(L, 0, 2); if (rc == HC_OK) rc = launch_collide(L, L->nx - 2, 2); }
+  if (rc == HC_OK && L->n_slabs > 1 && (part == 0 || part == 2 || part == 4) && L->ibm) {
     // the kernel zeroes the other-parity IBM force on the bulk planes; envelope copies of cells also
     // spread onto the halo planes, which have to be cleared as well (one small launch)
     hipLaunchKernelGGL(zero_force_halo_kernel, dim3((unsigned)((L->plane + 255) / 256), (unsigned)(2 * HALO * 3), 1), dim3(256), 0, hc::stream(),
@@ -682,14 +685,14 @@ size_t hcl_halo_doubles(const hc_lattice *L, int width) {
 // width 1 (every step): the 5 populations that cross the face.  width 2 (before interpolation): everything the
 // neighbour needs to evaluate node velocities on its first halo plane -- all 19 populations of the face plane plus,
 // from the plane behind it, the 5 that stream onto that halo plane.
-static int halo_copy(hc_lattice *L, int side, int width, double *buf, int to_buf) {
+static int halo_copy(hc_lattice *L, int side, int width, double *buf, int to_buf, int next = 0) {
   HC_REQUIRE(L && buf, "hcl_halo: null pointer");
   HC_REQUIRE((side == 0 || side == 1) && (width == 1 || width == 2), "hcl_halo: side must be 0/1 and width 1/2");
   HC_REQUIRE(L->nx >= 2 * width, "hcl_halo: slab thinner than the halo");
   static const int cxm[5] = {1, 4, 5, 6, 7};        // c_x = -1
   static const int cxp[5] = {10, 13, 14, 15, 16};   // c_x = +1
   HaloArgs h;
-  h.f = L->f[L->cur]; h.buf = buf; h.npad = (long)L->npad; h.plane = (int)L->plane; h.to_buf = to_buf; h.n = 0;
+  h.f = L->f[next ? 1 - L->cur : L->cur]; h.buf = buf; h.npad = (long)L->npad; h.plane = (int)L->plane; h.to_buf = to_buf; h.n = 0;
   // the populations that travel towards -x (cxm) leave through the low face and arrive in the low neighbour's high
   // halo; those towards +x (cxp) the other way round
   const int *moving = to_buf ? (side == 0 ? cxm : cxp) : (side == 0 ? cxp : cxm);
@@ -707,6 +710,7 @@ static int halo_copy(hc_lattice *L, int side, int width, double *buf, int to_buf
   return HC_OK;
 }
 int hcl_halo_pack(hc_lattice *L, int side, int width, double *dev_buf) { return halo_copy(L, side, width, dev_buf, 1); }
+int hcl_halo_pack_next(hc_lattice *L, int side, int width, double *dev_buf) { return halo_copy(L, side, width, dev_buf, 1, 1); }
 int hcl_halo_unpack(hc_lattice *L, int side, int width, const double *dev_buf) { return halo_copy(L, side, width, (double *)dev_buf, 0); }
 
 double hcl_mlups_bytes_per_node(const hc_lattice *L) {

@@ -85,8 +85,8 @@ class HipEngine:
     def halo_buffer(self, width):
         return torch.empty(self.L.halo_doubles(width), dtype=torch.float64, device=self.device)
 
-    def halo_pack(self, side, width, buf):
-        self.L.halo_pack(side, width, buf.data_ptr())
+    def halo_pack(self, side, width, buf, next=False):
+        self.L.halo_pack(side, width, buf.data_ptr(), next)
 
     def halo_unpack(self, side, width, buf):
         self.L.halo_unpack(side, width, buf.data_ptr())
@@ -194,6 +194,7 @@ class SlabProtocol:
         self.overlap = overlap
         self._hb = {}
         self._hdr = {}
+        self._pending = None     # completion of a face exchange in flight
         self.stats = {"cells_sent": 0, "cells_new": 0, "cells_dropped": 0}
 
     # ------------------------------------------------------------------ fluid halos
@@ -202,12 +203,15 @@ class SlabProtocol:
             self._hb[width] = [self.e.halo_buffer(width) for _ in range(4)]
         return self._hb[width]
 
-    def halo_exchange_begin(self, width):
+    def halo_exchange_begin(self, width, next=False):
+        """pack the faces and start the transfers; returns the callable that completes them (wait + unpack).
+        next: pack from the buffer the collide in progress is writing (its face planes are already done)."""
+        self.halo_drain()
         s_lo, s_hi, r_lo, r_hi = self._bufs(width)
         if self.comm.lo is not None:
-            self.e.halo_pack(0, width, s_lo)
+            self.e.halo_pack(0, width, s_lo, next)
         if self.comm.hi is not None:
-            self.e.halo_pack(1, width, s_hi)
+            self.e.halo_pack(1, width, s_hi, next)
         wait = self.comm.exchange(s_lo, s_hi, r_lo, r_hi)
 
         def finish():
@@ -317,31 +321,53 @@ class SlabProtocol:
         self.halo_exchange_begin(2)()
         self.halo_fresh = True
 
+    def halo_drain(self):
+        """complete a face exchange that was started at the end of the previous step"""
+        if self._pending is not None:
+            fin, self._pending = self._pending, None
+            fin()
+            self.halo_fresh = True
+
     def step(self):
+        """No transfer is waited for while there is independent work left: the 5 crossing populations of a face leave
+        right after the collide that produced them and travel during advance, mechanics, the next spread and the next
+        interior collide; the wider message an interpolation needs leaves as soon as the two planes next to each face
+        are collided and travels during the interior collide of the same step."""
         e = self.e
         it = self.iter
-        if it % self.k_p == 0:
+        particle_step = it % self.k_p == 0
+        if particle_step:
             self.plan_cells()                                 # extents for the envelope sync at the end of this step
         e.repulsion(it)                                       # core/hemoCell.cpp:307-312
         e.spread()                                            # :313
-        if self.halo_fresh:
-            e.collide(0)                                      # :317
+        if not self.overlap:                                  # :317
+            if not self.halo_fresh:
+                self.halo_exchange_begin(1)()
+            e.collide(0)
+            e.step_end()
+            if particle_step:
+                self.halo_exchange_begin(2)()
+        elif particle_step:
+            self.halo_drain()
+            e.collide(4)                                      # the two planes next to each face first ...
+            finish = self.halo_exchange_begin(2, next=True)   # ... so that they travel while the interior is collided
+            e.collide(3)
+            e.step_end()
+            finish()
         else:
-            finish = self.halo_exchange_begin(1)
-            if self.overlap:
-                e.collide(1)                                  # interior planes while the faces are in flight
-                finish()
-                e.collide(2)
-            else:
-                finish()
+            if self.halo_fresh:
                 e.collide(0)
-        e.step_end()
-        self.halo_fresh = False
-        if it % self.k_p == 0:                                # :327-332
-            self.halo_exchange_begin(2)()                     # full planes: velocities are interpolated at halo nodes too
-            self.halo_fresh = True
-            e.interpolate()
+            else:
+                e.collide(1)                                  # interior planes while the faces are in flight
+                self.halo_drain()
+                e.collide(2)
+            e.step_end()
+        self.halo_fresh = particle_step
+        if particle_step:                                     # :327-332
+            e.interpolate()                                   # velocities are interpolated at halo nodes too
             self.sync_cells()
+        elif self.overlap:
+            self._pending = self.halo_exchange_begin(1)       # faces of the state just written, needed by the next collide
         e.advance()                                           # :342
         e.mechanics(it)                                       # :345
         self.iter = it + 1

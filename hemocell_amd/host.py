@@ -136,8 +136,9 @@ class Lattice:
     def halo_doubles(self, width):
         return int(self.lib.hcl_halo_doubles(self.ptr, int(width)))
 
-    def halo_pack(self, side, width, dev_ptr):
-        check(self.lib.hcl_halo_pack(self.ptr, int(side), int(width), C.c_void_p(dev_ptr)))
+    def halo_pack(self, side, width, dev_ptr, next=False):
+        fn = self.lib.hcl_halo_pack_next if next else self.lib.hcl_halo_pack
+        check(fn(self.ptr, int(side), int(width), C.c_void_p(dev_ptr)))
 
     def halo_unpack(self, side, width, dev_ptr):
         check(self.lib.hcl_halo_unpack(self.ptr, int(side), int(width), C.c_void_p(dev_ptr)))

@@ -77,7 +77,9 @@ int hcl_set_wall_velocity(hc_lattice *L, int wall_class, const double u[3]);
 /* lattice->collideAndStream() (core/hemoCell.cpp:317), n times (fluid-only stepping; n_slabs==1) */
 int hcl_collide_stream(hc_lattice *L, int nsteps);
 /* one collide-stream of this slab; halos must be current. part: 0 = all planes, 1 = interior planes
- * (those that do not read halo data), 2 = the boundary planes.  hcl_step_end() flips the buffers. */
+ * (those that do not read halo data), 2 = the two face planes; or 3 = planes 2..nx-3, 4 = the two planes next to each
+ * face (what a width-2 halo message is packed from, so that it can travel while part 3 runs).
+ * hcl_step_end() flips the buffers. */
 int hcl_collide_stream_part(hc_lattice *L, int part);
 int hcl_step_end(hc_lattice *L);
 /* populations in the reference's own layout: AoS [node][19], node = z + nz*(y + ny*x), values f_i - t_i
@@ -102,6 +104,9 @@ int hcl_zero_ibm_force(hc_lattice *L);
 size_t hcl_halo_doubles(const hc_lattice *L, int width);
 int hcl_halo_pack(hc_lattice *L, int side, int width, double *dev_buf);
 int hcl_halo_unpack(hc_lattice *L, int side, int width, const double *dev_buf);
+/* as hcl_halo_pack, but from the buffer the collide-stream in progress is writing (between
+ * hcl_collide_stream_part(L, 4) and hcl_step_end): lets the message leave before the interior planes are done */
+int hcl_halo_pack_next(hc_lattice *L, int side, int width, double *dev_buf);
 int hcl_dims(const hc_lattice *L, int dims[3]);
 double hcl_mlups_bytes_per_node(const hc_lattice *L); /* algorithmic bytes per node update of the collide kernel */
 

@@ -30,9 +30,9 @@ class FakeEngine:
         cxm, cxp = [1, 4, 5, 6, 7], [10, 13, 14, 15, 16]
         return (cxm if side == 0 else cxp) if to_buf else (cxp if side == 0 else cxm)
 
-    def halo_pack(self, side, width, buf):
+    def halo_pack(self, side, width, buf, next=False):
         xf = HALO if side == 0 else HALO + self.nx - width
-        a = self.f[self.cur][self._pops(width, True, side), xf:xf + width, :]
+        a = self.f[1 - self.cur if next else self.cur][self._pops(width, True, side), xf:xf + width, :]
         buf.copy_(torch.from_numpy(np.ascontiguousarray(a).reshape(-1)))
 
     def halo_unpack(self, side, width, buf):
@@ -41,7 +41,8 @@ class FakeEngine:
         self.f[self.cur][pops, xf:xf + width, :] = buf.numpy().reshape(len(pops), width, self.plane)
 
     def collide(self, part):
-        xs = {0: range(self.nx), 1: range(1, self.nx - 1), 2: [0, self.nx - 1]}[part]
+        xs = {0: range(self.nx), 1: range(1, self.nx - 1), 2: [0, self.nx - 1], 3: range(2, self.nx - 2),
+              4: [0, 1, self.nx - 2, self.nx - 1]}[part]
         fin, fout = self.f[self.cur], self.f[1 - self.cur]
         for x in xs:
             for q in range(19):

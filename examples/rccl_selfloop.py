@@ -51,7 +51,29 @@ def timeit(fn, k):
 L1, h1 = build(1)
 h1.iterate(20); t_iter = timeit(lambda k: h1.iterate(k), steps)
 f_ref = L1.populations(); p_ref = h1.cellfields.positions.copy()
+h1.setParticleVelocityUpdateTimeScaleSeparation(10**9)
+h1.iterate(10); t_iter_nop = timeit(lambda k: h1.iterate(k), steps)
 L1.destroy()
+
+
+class Loopback:
+    """same protocol, transport = two device copies on the compute stream (no RCCL)"""
+    rank, world, lo, hi, backend = 0, 1, 0, 0, "loopback"
+
+    def exchange(self, send_lo, send_hi, recv_lo, recv_hi):
+        if send_lo is not None and send_lo.numel():
+            recv_hi.copy_(send_lo)
+        if send_hi is not None and send_hi.numel():
+            recv_lo.copy_(send_hi)
+        return lambda: None
+
+
+def issue_time(fn, k):
+    """host time to enqueue k steps (the GPU is still busy when this returns unless the host is the bottleneck)"""
+    torch.cuda.synchronize(); lib.hc_synchronize()
+    t0 = time.perf_counter(); fn(k); t1 = time.perf_counter()
+    torch.cuda.synchronize(); lib.hc_synchronize()
+    return (t1 - t0) / k * 1e3
 
 L2, h2 = build(2)
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream); host.check(lib.hc_set_stream(stream.cuda_stream))
@@ -70,4 +92,24 @@ print("RCCL self-loop, %d^3 pipe, %d cells, %d steps: hc_iterate %.4f ms/step, s
       % (n, len(centres), steps + 20, t_iter, t_rccl, (t_rccl / t_iter - 1) * 100))
 print("max |df| = %.3e   max |dx| = %.3e lu" % (err_f, err_p), flush=True)
 assert err_f <= 1e-10 and err_p <= 1e-8, (err_f, err_p)
+# where the difference comes from: without the envelope sync, and without any particle update at all
+real_sync = proto.sync_cells_begin, proto.sync_cells_finish
+proto.sync_cells_begin, proto.sync_cells_finish = (lambda: None), (lambda plans: None)
+proto.run(10); t_nosync = timeit(lambda k: proto.run(k), steps)
+proto.sync_cells_begin, proto.sync_cells_finish = real_sync
+proto.k_p = 10**9
+proto.run(10); t_nop = timeit(lambda k: proto.run(k), steps)
+t_issue = issue_time(lambda k: proto.run(k), steps)
+proto.overlap = False
+proto.run(10); t_nop_serial = timeit(lambda k: proto.run(k), steps)
+proto.overlap = True
+proto.comm = Loopback()
+proto.run(10); t_nop_loop = timeit(lambda k: proto.run(k), steps)
+t_issue_loop = issue_time(lambda k: proto.run(k), steps)
+proto.k_p = 5
+proto.run(10); t_loop = timeit(lambda k: proto.run(k), steps)
+print("hc_iterate        : %.4f (k_p=5)  %.4f (no particle update)" % (t_iter, t_iter_nop))
+print("protocol, loopback: %.4f (k_p=5)  %.4f (face messages only; host issue time %.4f)" % (t_loop, t_nop_loop, t_issue_loop))
+print("protocol over RCCL: %.4f (k_p=5)  %.4f (k_p=5, sync_cells skipped)  %.4f (face messages only; host issue time %.4f)  %.4f (face messages only, not overlapped)"
+      % (t_rccl, t_nosync, t_nop, t_issue, t_nop_serial), flush=True)
 dist.destroy_process_group()

@@ -231,22 +231,29 @@ class SlabProtocol:
             self.e.cell_extents_begin(t)
 
     def _header_buffers(self, t):
-        """fixed-size id headers of type t: [host staging, device send, device receive] per side, made once"""
+        """fixed-size id headers of type t: [host staging, device send, device receive, host landing] per side, made once"""
         if t not in self._hdr:
             dev = self._dev()
             pin = dev != "cpu"
             self._hdr[t] = [(torch.zeros(MAX_SHARED, dtype=torch.int64, pin_memory=pin),
                              torch.zeros(MAX_SHARED, dtype=torch.int64, device=dev),
-                             torch.zeros(MAX_SHARED, dtype=torch.int64, device=dev)) for _ in (0, 1)]
+                             torch.zeros(MAX_SHARED, dtype=torch.int64, device=dev),
+                             torch.zeros(MAX_SHARED, dtype=torch.int64, pin_memory=pin)) for _ in (0, 1)]
         return self._hdr[t]
 
     def sync_cells(self):
+        self.sync_cells_finish(self.sync_cells_begin())
+
+    def sync_cells_begin(self):
+        """first half of the envelope sync, everything that only depends on the positions: which cells cross which
+        face, and the exchange of the id headers.  The received headers are copied to pinned host memory behind an
+        event, so that the host round trip can hide behind the interpolation kernel that is enqueued next."""
         e, comm = self.e, self.comm
         x0, x1 = e.x0, e.x0 + e.nx
+        plans = []
         for t in range(e.n_types()):
             ext = e.cell_extents(t)
             ids = np.asarray(e.cell_ids(t), dtype=np.int64)
-            n = len(ids)
             send = {}
             for side, nb in ((0, comm.lo), (1, comm.hi)):
                 if nb is None:
@@ -265,16 +272,34 @@ class SlabProtocol:
                                         % (max(len(send[0][0]), len(send[1][0])), MAX_SHARED - 1))
             hdr = self._header_buffers(t)
             for side in (0, 1):
-                stage, dev_s, _ = hdr[side]
+                stage, dev_s, _, _ = hdr[side]
                 k = len(send[side][0])
                 hh = stage.numpy()
                 hh[0] = k; hh[1:1 + k] = send[side][1]
                 dev_s[:1 + k].copy_(stage[:1 + k], non_blocking=True)
             comm.exchange(hdr[0][1], hdr[1][1], hdr[0][2], hdr[1][2])()
-            hr = [hdr[0][2].cpu().numpy() if comm.lo is not None else np.zeros(1, np.int64),
-                  hdr[1][2].cpu().numpy() if comm.hi is not None else np.zeros(1, np.int64)]
+            ready = None
+            for side, nb in ((0, comm.lo), (1, comm.hi)):
+                if nb is not None:
+                    hdr[side][3].copy_(hdr[side][2], non_blocking=True)
+            if self._dev() != "cpu":
+                ready = torch.cuda.Event()
+                ready.record()
+            plans.append((t, ext, ids, send, ready))
+        return plans
+
+    def sync_cells_finish(self, plans):
+        """second half: records of the crossing cells (they carry the velocities just interpolated), merge, drop"""
+        e, comm = self.e, self.comm
+        for t, ext, ids, send, ready in plans:
+            n = len(ids)
+            hdr = self._header_buffers(t)
+            if ready is not None:
+                ready.synchronize()
+            hr = [hdr[0][3].numpy() if comm.lo is not None else np.zeros(1, np.int64),
+                  hdr[1][3].numpy() if comm.hi is not None else np.zeros(1, np.int64)]
             n_lo, n_hi = int(hr[0][0]), int(hr[1][0])
-            ids_r = [hr[0][1:1 + n_lo], hr[1][1:1 + n_hi]]
+            ids_r = [hr[0][1:1 + n_lo].copy(), hr[1][1:1 + n_hi].copy()]
             # phase 2: records
             shift_lo = float(self.nx_global) if (self.periodic_x and comm.rank == 0) else 0.0          # crossing the seam downward
             shift_hi = -float(self.nx_global) if (self.periodic_x and comm.rank == comm.world - 1) else 0.0
@@ -364,8 +389,9 @@ class SlabProtocol:
             e.step_end()
         self.halo_fresh = particle_step
         if particle_step:                                     # :327-332
-            e.interpolate()                                   # velocities are interpolated at halo nodes too
-            self.sync_cells()
+            plans = self.sync_cells_begin()                   # id headers travel and land on the host ...
+            e.interpolate()                                   # ... while velocities are interpolated (at halo nodes too)
+            self.sync_cells_finish(plans)
         elif self.overlap:
             self._pending = self.halo_exchange_begin(1)       # faces of the state just written, needed by the next collide
         e.advance()                                           # :342

@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--periodic-box", action="store_true",
                     help="cases/performance_testing geometry: fully periodic box, no walls, tau = 1, body force on all axes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="A/B: one stream only (by default advance, mechanics and the next spread run beside the collide between velocity updates)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -130,6 +132,8 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     host.init(local_rank)
+    if args.no_overlap:
+        host.capi.check(host.capi.lib().hc_set_overlap(0))
 
     # examples/pipeflow/config.xml:25-28: dx 5e-7, dt 1e-7, nuP 1.1e-6 -> tau 1.82; performance_testing: dt = -1 -> tau = 1
     P = host.base_parameters(dt=-1.0) if args.periodic_box else host.base_parameters()
@@ -138,6 +142,8 @@ def main():
                         periodic=(True, True, True) if args.periodic_box else (True, False, False),
                         particle_timescale=5, material_timescale=20,
                         deletion_check_every=1000000, fluid_only=args.fluid_only or args.periodic_box)
+    if args.no_overlap and runner.exchange is not None:
+        runner.exchange.protocol.overlap = False
     mask, R = host.pipe_mask(nxg, args.ny, args.nz)
     if args.periodic_box:
         mask[:] = 0

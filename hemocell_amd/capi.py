@@ -39,6 +39,10 @@ SIGNATURES = {
     "hc_device_count": (C.c_int, [c_int_p]),
     "hc_set_stream": (C.c_int, [VP]),
     "hc_synchronize": (C.c_int, []),
+    "hc_fork": (C.c_int, []),
+    "hc_route": (C.c_int, [C.c_int]),
+    "hc_join": (C.c_int, []),
+    "hc_set_overlap": (C.c_int, [C.c_int]),
     "hc_profile_enable": (C.c_int, [C.c_int]),
     "hc_profile_read": (C.c_int, [C.c_char_p, c_double_p, c_long_p]),
     "hc_profile_reset": (C.c_int, []),

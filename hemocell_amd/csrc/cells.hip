@@ -552,22 +552,44 @@ int hcp_advance(hc_cells *C, int check_deletions) {
   return HC_OK;
 }
 
+static int g_overlap = 1;   // hc_iterate: run advance + mechanics + the next spread beside the collide on steps without a particle update
+int hc_set_overlap(int on) { g_overlap = on != 0; return HC_OK; }
+
 int hc_iterate(hc_lattice *L, hc_cells *C, long *iter, int n, int particle_timescale, int force_limit, int deletion_check_every) {
   HC_REQUIRE(L && C && iter, "hc_iterate: null pointer");
   HC_REQUIRE(C->L == L, "hc_iterate: cells are bound to a different lattice");
   HC_REQUIRE(L->n_slabs == 1, "hc_iterate: single-slab stepping only; multi-slab runs are driven phase by phase with halo exchange");
   HC_REQUIRE(particle_timescale >= 1 && deletion_check_every >= 1, "hc_iterate: timescales must be >= 1");
+  // Same phases in the same order as HemoCell::iterate.  Between two velocity updates advance(it), mechanics(it) and
+  // spread(it+1) depend only on vertex data, not on collide(it): they run on the side stream beside it (the spread
+  // adds into the force buffer of the next step, which the previous collide left clean).  Never across the end of
+  // the call: the caller may edit vertex forces between calls (HemoCellStretch does).
+  struct RouteGuard { ~RouteGuard() { hc::route(0); } } guard;
+  const bool may_overlap = g_overlap && !C->rep_enabled && !C->brep_enabled;
+  bool spread_done = false;
   int rc;
   for (int s = 0; s < n; s++) {
     const long it = *iter;
-    if (C->rep_enabled && it % C->rep_timescale == 0) { if ((rc = hcp_repulsion(C)) != HC_OK) return rc; }   // core/hemoCell.cpp:307-309
-    if (C->brep_enabled && it % C->brep_timescale == 0) { if ((rc = hcp_boundary_repulsion(C)) != HC_OK) return rc; }   // :310-312
-    if ((rc = hcp_spread(C, force_limit)) != HC_OK) return rc;                  // :313
+    if (!spread_done) {
+      if (C->rep_enabled && it % C->rep_timescale == 0) { if ((rc = hcp_repulsion(C)) != HC_OK) return rc; }   // core/hemoCell.cpp:307-309
+      if (C->brep_enabled && it % C->brep_timescale == 0) { if ((rc = hcp_boundary_repulsion(C)) != HC_OK) return rc; }   // :310-312
+      if ((rc = hcp_spread(C, force_limit)) != HC_OK) return rc;                // :313
+    }
+    spread_done = false;
+    const bool particle_step = it % particle_timescale == 0, check = (it % deletion_check_every) == 0;
+    const bool overlap = may_overlap && !particle_step && !check && s + 1 < n;
+    if (overlap && (rc = hc::fork()) != HC_OK) return rc;
     if ((rc = hcl_collide_stream_part(L, 0)) != HC_OK) return rc;               // :317
     hcl_step_end(L);
-    if (it % particle_timescale == 0) { if ((rc = hcp_interpolate(C)) != HC_OK) return rc; }   // :327-332
-    if ((rc = hcp_advance(C, (it % deletion_check_every) == 0)) != HC_OK) return rc;           // :342
+    if (particle_step) { if ((rc = hcp_interpolate(C)) != HC_OK) return rc; }   // :327-332
+    if (overlap) hc::route(1);
+    if ((rc = hcp_advance(C, check)) != HC_OK) return rc;                       // :342
     if ((rc = hcp_mechanics(C, it, 0)) != HC_OK) return rc;                     // :345
+    if (overlap) {
+      if ((rc = hcp_spread(C, force_limit)) != HC_OK) return rc;                // :313 of iteration it + 1
+      if ((rc = hc::join()) != HC_OK) return rc;
+      spread_done = true;
+    }
     *iter = it + 1;                                                             // :374 (force zeroing is fused into the collide kernel)
   }
   return HC_OK;

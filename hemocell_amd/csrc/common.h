@@ -11,6 +11,11 @@ namespace hc {
 void set_error(const std::string &msg);
 int hip_fail(hipError_t e, const char *what, const char *file, int line);
 hipStream_t stream();
+// fork-join onto the library's side stream: fork() makes the side stream wait for everything enqueued so far,
+// route(1) sends the following launches there, route(0) back, join() makes the main stream wait for them
+int fork();
+void route(int side);
+int join();
 
 #define HC_HIP(call)                                                         \
   do {                                                                       \
@@ -81,15 +86,17 @@ struct hc_lattice {
   size_t npad;           // (nx+2*HALO)*plane
   double *f[2];          // [19][npad] post-collision populations (fBar), ping-pong
   int cur;               // f[cur] is read by the next collide
-  double *force[2];      // [3][npad] IBM force accumulators, ping-pong
-  int fcur;              // force[fcur] is the one spread adds to / collide reads
+  double *force[3];      // [3][npad] IBM force accumulators, rotated: fcur -> (fcur+1)%3 every step
+  int fcur;              // force[fcur] is the one spread adds to / collide reads; force[(fcur+2)%3] is the previous
+                         // step's (what the interpolation after a collide reads, and what the NEXT collide zeroes);
+                         // force[(fcur+1)%3] is already clean, so the spread of the next step may run beside this collide
   int ibm;               // set once membrane cells are bound (hcp_create): collide then reads/zeroes the force buffers
   // dirty map of the IBM force buffers: one byte per group of 16 consecutive nodes (one 128-byte line of a
   // force component) holding the epoch in which spread last touched the group.  The collide kernel reads /
   // zeroes a group only when its byte equals the buffer's current epoch, so untouched lines cost no traffic.
   // Epochs are never cleared (no races); an aliased stale epoch only causes a harmless extra read / zeroing.
-  uint8_t *fdirty[2];
-  uint8_t fepoch[2];
+  uint8_t *fdirty[3];
+  uint8_t fepoch[3];
   uint8_t *mask;         // [npad]
   std::vector<uint8_t> hmask;  // host copy (cell placement tests against it)
   double body[3];

@@ -410,8 +410,8 @@ int hcp_interpolate(hc_cells *C) {
   hc::ProfScope prof(hc::PK_INTERP);
   const hc_lattice *L = C->L;
   const LatView v = make_view(L);
-  // state after hcl_step_end: f[cur] holds the populations just written, force[1-fcur] the force they were collided with
-  PopView pv{L->f[L->cur], L->force[1 - L->fcur], L->body[0], L->body[1], L->body[2]};
+  // state after hcl_step_end: f[cur] holds the populations just written, force[(fcur+2)%3] the force they were collided with
+  PopView pv{L->f[L->cur], L->force[(L->fcur + 2) % 3], L->body[0], L->body[1], L->body[2]};
   for (int t = 0; t < C->ntypes; t++) {
     const long n = C->ncells[t] * C->types[t]->host.nv, f = C->first[t];
     if (n == 0) continue;

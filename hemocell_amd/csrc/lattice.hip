@@ -364,7 +364,8 @@ __global__ void zero_force_halo_kernel(double *F, long npad, int plane, int nx) 
 LatArgs make_args(const hc_lattice *L) {
   LatArgs a;
   a.fin = L->f[L->cur]; a.fout = L->f[1 - L->cur];
-  a.Fin = L->force[L->fcur]; a.Fzero = L->force[1 - L->fcur];
+  const int fprev = (L->fcur + 2) % 3;
+  a.Fin = L->force[L->fcur]; a.Fzero = L->force[fprev];
   a.mask = L->mask;
   a.nx = L->nx; a.ny = L->ny; a.nz = L->nz; a.plane = (int)L->plane; a.npad = (long)L->npad;
   a.x_begin = 0;
@@ -373,7 +374,7 @@ LatArgs make_args(const hc_lattice *L) {
   a.omega = L->omega; a.bx = L->body[0]; a.by = L->body[1]; a.bz = L->body[2];
   a.row_z0 = L->row_z0; a.row_cum = L->row_cum; a.blk_row = L->blk_row; a.nblk = L->nblk;
   a.ibm = L->ibm;
-  a.dirty_in = L->fdirty[L->fcur]; a.dirty_zero = L->fdirty[1 - L->fcur]; a.epoch_in = L->fepoch[L->fcur]; a.epoch_zero = L->fepoch[1 - L->fcur];
+  a.dirty_in = L->fdirty[L->fcur]; a.dirty_zero = L->fdirty[fprev]; a.epoch_in = L->fepoch[L->fcur]; a.epoch_zero = L->fepoch[fprev];
   for (int c = 0; c < 4; c++) for (int d = 0; d < 3; d++) a.wall_u[c][d] = L->wall_u[c][d];
   return a;
 }
@@ -463,16 +464,19 @@ int hcl_create(hc_lattice **out, int nx, int ny, int nz, const int periodic[3], 
   L->body[0] = L->body[1] = L->body[2] = 0.0;
   for (int c = 0; c < 4; c++) for (int d = 0; d < 3; d++) L->wall_u[c][d] = 0.0;
   L->scratch = nullptr; L->scratch_doubles = 0;
-  L->f[0] = L->f[1] = L->force[0] = L->force[1] = nullptr; L->mask = nullptr; L->fdirty[0] = L->fdirty[1] = nullptr;
+  L->f[0] = L->f[1] = nullptr; L->mask = nullptr;
+  for (int k = 0; k < 3; k++) { L->force[k] = nullptr; L->fdirty[k] = nullptr; }
   for (int k = 0; k < 2; k++) {
     HC_HIP(hipMalloc((void **)&L->f[k], L->npad * HC_Q * sizeof(double)));
     HC_HIP(hipMemsetAsync(L->f[k], 0, L->npad * HC_Q * sizeof(double), hc::stream()));
+  }
+  for (int k = 0; k < 3; k++) {
     HC_HIP(hipMalloc((void **)&L->force[k], L->npad * 3 * sizeof(double)));
     HC_HIP(hipMemsetAsync(L->force[k], 0, L->npad * 3 * sizeof(double), hc::stream()));
   }
   HC_HIP(hipMalloc((void **)&L->mask, L->npad));
   HC_HIP(hipMemsetAsync(L->mask, 0, L->npad, hc::stream()));
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < 3; k++) {
     HC_HIP(hipMalloc((void **)&L->fdirty[k], L->npad / 16 + 1));
     HC_HIP(hipMemsetAsync(L->fdirty[k], 0, L->npad / 16 + 1, hc::stream()));
     L->fepoch[k] = 1;
@@ -488,7 +492,8 @@ int hcl_create(hc_lattice **out, int nx, int ny, int nz, const int periodic[3], 
 int hcl_destroy(hc_lattice *L) {
   if (!L) return HC_OK;
   hipStreamSynchronize(hc::stream());
-  for (int k = 0; k < 2; k++) { if (L->f[k]) hipFree(L->f[k]); if (L->force[k]) hipFree(L->force[k]); if (L->fdirty[k]) hipFree(L->fdirty[k]); }
+  for (int k = 0; k < 2; k++) if (L->f[k]) hipFree(L->f[k]);
+  for (int k = 0; k < 3; k++) { if (L->force[k]) hipFree(L->force[k]); if (L->fdirty[k]) hipFree(L->fdirty[k]); }
   if (L->mask) hipFree(L->mask);
   if (L->scratch) hipFree(L->scratch);
   if (L->row_z0) hipFree(L->row_z0);
@@ -588,7 +593,7 @@ int hcl_collide_stream_part(hc_lattice *L, int part) {
     // the kernel zeroes the other-parity IBM force on the bulk planes; envelope copies of cells also
     // spread onto the halo planes, which have to be cleared as well (one small launch)
     hipLaunchKernelGGL(zero_force_halo_kernel, dim3((unsigned)((L->plane + 255) / 256), (unsigned)(2 * HALO * 3), 1), dim3(256), 0, hc::stream(),
-                       L->force[1 - L->fcur], (long)L->npad, (int)L->plane, L->nx);
+                       L->force[(L->fcur + 2) % 3], (long)L->npad, (int)L->plane, L->nx);
     HC_HIP(hipGetLastError());
   }
   return rc;
@@ -596,7 +601,7 @@ int hcl_collide_stream_part(hc_lattice *L, int part) {
 
 int hcl_step_end(hc_lattice *L) {
   HC_REQUIRE(L, "hcl_step_end: null lattice");
-  L->cur ^= 1; L->fcur ^= 1;
+  L->cur ^= 1; L->fcur = (L->fcur + 1) % 3;
   L->fepoch[L->fcur] = (uint8_t)(L->fepoch[L->fcur] % 255 + 1);   // the buffer spread will add to next gets a fresh epoch (1..255)
   return HC_OK;
 }

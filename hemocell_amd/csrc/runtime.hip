@@ -8,7 +8,10 @@ namespace hc {
 
 static thread_local std::string g_error;
 static hipStream_t g_own_stream = nullptr;
-static hipStream_t g_stream = nullptr;
+static hipStream_t g_stream = nullptr;       // main stream (own, or the caller's through hc_set_stream)
+static hipStream_t g_side = nullptr;         // side stream of fork / join
+static hipEvent_t g_fork_ev = nullptr, g_join_ev = nullptr;
+static bool g_on_side = false;
 static bool g_initialised = false;
 static bool g_profile = false;
 
@@ -22,16 +25,28 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
   g_error = std::string("HIP error ") + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ") in " + what + " at " + file + ":" + std::to_string(line);
   return HC_ERR_HIP;
 }
-hipStream_t stream() { return g_stream; }
+hipStream_t stream() { return g_on_side ? g_side : g_stream; }
+int fork() {
+  HC_HIP(hipEventRecord(g_fork_ev, g_stream));
+  HC_HIP(hipStreamWaitEvent(g_side, g_fork_ev, 0));
+  return HC_OK;
+}
+void route(int side) { g_on_side = side != 0; }
+int join() {
+  g_on_side = false;
+  HC_HIP(hipEventRecord(g_join_ev, g_side));
+  HC_HIP(hipStreamWaitEvent(g_stream, g_join_ev, 0));
+  return HC_OK;
+}
 
 ProfScope::ProfScope(int kernel) : k(kernel), on(g_profile), a(nullptr), b(nullptr) {
   if (!on) return;
   if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
-  hipEventRecord(a, g_stream);
+  hipEventRecord(a, stream());
 }
 ProfScope::~ProfScope() {
   if (!on) return;
-  hipEventRecord(b, g_stream);
+  hipEventRecord(b, stream());
   g_prof[k].push_back({a, b});
 }
 
@@ -92,6 +107,11 @@ int hc_init(int device) {
   }
   if (!hc::g_own_stream) HC_HIP(hipStreamCreateWithFlags(&hc::g_own_stream, hipStreamNonBlocking));
   if (!hc::g_stream) hc::g_stream = hc::g_own_stream;
+  if (!hc::g_side) {
+    HC_HIP(hipStreamCreateWithFlags(&hc::g_side, hipStreamNonBlocking));
+    HC_HIP(hipEventCreateWithFlags(&hc::g_fork_ev, hipEventDisableTiming));
+    HC_HIP(hipEventCreateWithFlags(&hc::g_join_ev, hipEventDisableTiming));
+  }
   hc::g_initialised = true;
   return HC_OK;
 }
@@ -103,8 +123,13 @@ int hc_set_stream(void *hip_stream) {
 
 int hc_synchronize(void) {
   HC_HIP(hipStreamSynchronize(hc::g_stream));
+  if (hc::g_side) HC_HIP(hipStreamSynchronize(hc::g_side));
   return HC_OK;
 }
+
+int hc_fork(void) { return hc::fork(); }
+int hc_route(int side) { hc::route(side); return HC_OK; }
+int hc_join(void) { return hc::join(); }
 
 int hc_profile_enable(int on) { hc::g_profile = on != 0; return HC_OK; }
 int hc_profile_reset(void) {

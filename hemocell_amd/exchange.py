@@ -97,6 +97,15 @@ class HipEngine:
     def step_end(self):
         self.L.step_end()
 
+    def fork(self):
+        host.check(self.lib.hc_fork())
+
+    def route(self, side):
+        host.check(self.lib.hc_route(int(side)))
+
+    def join(self):
+        host.check(self.lib.hc_join())
+
     # ---- cells
     def n_types(self):
         return len(self.C.types) if self.C is not None else 0
@@ -195,6 +204,7 @@ class SlabProtocol:
         self._hb = {}
         self._hdr = {}
         self._pending = None     # completion of a face exchange in flight
+        self._spread_done = False   # the spread of the coming iteration already ran beside the last collide
         self.stats = {"cells_sent": 0, "cells_new": 0, "cells_dropped": 0}
 
     # ------------------------------------------------------------------ fluid halos
@@ -353,18 +363,25 @@ class SlabProtocol:
             fin()
             self.halo_fresh = True
 
-    def step(self):
+    def step(self, more=False):
         """No transfer is waited for while there is independent work left: the 5 crossing populations of a face leave
         right after the collide that produced them and travel during advance, mechanics, the next spread and the next
         interior collide; the wider message an interpolation needs leaves as soon as the two planes next to each face
-        are collided and travels during the interior collide of the same step."""
+        are collided and travels during the interior collide of the same step.  Between two velocity updates advance,
+        mechanics and the spread of the NEXT iteration do not depend on the collide: with more=True (another step
+        follows in the same run) they are put on the library's side stream beside it, as hc_iterate does."""
         e = self.e
         it = self.iter
         particle_step = it % self.k_p == 0
         if particle_step:
             self.plan_cells()                                 # extents for the envelope sync at the end of this step
-        e.repulsion(it)                                       # core/hemoCell.cpp:307-312
-        e.spread()                                            # :313
+        if not self._spread_done:
+            e.repulsion(it)                                   # core/hemoCell.cpp:307-312
+            e.spread()                                        # :313
+        self._spread_done = False
+        beside = self.overlap and more and not particle_step
+        if beside:
+            e.fork()
         if not self.overlap:                                  # :317
             if not self.halo_fresh:
                 self.halo_exchange_begin(1)()
@@ -394,13 +411,20 @@ class SlabProtocol:
             self.sync_cells_finish(plans)
         elif self.overlap:
             self._pending = self.halo_exchange_begin(1)       # faces of the state just written, needed by the next collide
+        if beside:
+            e.route(1)
         e.advance()                                           # :342
         e.mechanics(it)                                       # :345
+        if beside:
+            e.repulsion(it + 1)
+            e.spread()                                        # :313 of iteration it + 1
+            e.join()
+            self._spread_done = True
         self.iter = it + 1
 
     def run(self, n):
-        for _ in range(n):
-            self.step()
+        for k in range(n):
+            self.step(more=k + 1 < n)
 
 
 class SlabExchange:

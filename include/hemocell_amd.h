@@ -45,6 +45,15 @@ int hc_device_count(int *count);
 /* run every kernel of this library on an existing hipStream_t (e.g. the host framework's current stream); NULL = library stream */
 int hc_set_stream(void *hip_stream);
 int hc_synchronize(void);
+/* fork-join onto a second stream owned by the library, for phase-by-phase callers (slab runs) that want what
+ * hc_iterate does on its own: hc_fork() makes the side stream wait for everything enqueued so far, hc_route(1) sends the
+ * launches of the following calls there (hc_route(0): back to the main stream), hc_join() makes the main stream wait
+ * for them.  Between two velocity updates advance, mechanics and the next spread run beside the collide this way. */
+int hc_fork(void);
+int hc_route(int side);
+int hc_join(void);
+/* hc_iterate overlaps those phases by itself (default); 0 = strictly one stream (A/B measurements) */
+int hc_set_overlap(int on);
 /* per-launch hipEvent timing of the dominant kernel (helper/profiler.h:46-77 "collideAndStream" timer) */
 int hc_profile_enable(int on);
 int hc_profile_read(const char *kernel, double *total_ms, long *launches); /* "collide_stream", "ibm_spread", "ibm_interpolate", "advance", "mechanics" */

@@ -51,6 +51,15 @@ class FakeEngine:
     def step_end(self):
         self.cur ^= 1
 
+    def fork(self):
+        pass
+
+    def route(self, side):
+        pass
+
+    def join(self):
+        pass
+
     def post_stream(self):
         """S(x,q) = P(x - c_q, q) on the bulk planes"""
         fin = self.f[self.cur]

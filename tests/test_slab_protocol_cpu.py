@@ -51,8 +51,8 @@ def _worker(rank, world, port, periodic, steps, k_p, out):
     proto = SlabProtocol(e, comm, k_p, nxg, periodic)
     proto.prepare()
     total_owned = []
-    for _ in range(steps):
-        proto.step()
+    for k in range(steps):
+        proto.step(more=k + 1 < steps)
         t = torch.tensor([e.owned_vertices()]); dist.all_reduce(t); total_owned.append(int(t))
         assert not np.isnan(e.pos).any(), "a vertex advanced with a velocity nobody owned"
     proto.halo_exchange_begin(2)()   # the post-stream view pulls from the halo planes: refresh them first

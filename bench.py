@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--periodic-box", action="store_true",
                     help="cases/performance_testing geometry: fully periodic box, no walls, tau = 1, body force on all axes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true", help="A/B: no per-kernel hipEvent brackets in the timed region (roofline fields are then empty)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="A/B: one stream only (by default advance, mechanics and the next spread run beside the collide between velocity updates)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -177,7 +178,7 @@ def main():
 
     runner.run(args.warmup)
     host.capi.lib().hc_profile_reset()
-    host.capi.lib().hc_profile_enable(1)
+    host.capi.lib().hc_profile_enable(0 if args.no_kernel_profile else 1)
     barrier()
     t0 = time.perf_counter()
     runner.run(args.steps)
@@ -198,7 +199,7 @@ def main():
     ms, n = C.c_double(), C.c_long()
     host.capi.check(host.capi.lib().hc_profile_read(b"collide_stream", C.byref(ms), C.byref(n)))
     prof = {}
-    for k in ("collide_stream", "ibm_spread", "ibm_interpolate", "advance", "mechanics"):
+    for k in ("collide_stream", "collide_stream_alone", "collide_stream_beside", "ibm_spread", "ibm_interpolate", "advance", "mechanics"):
         m2, n2 = C.c_double(), C.c_long()
         host.capi.check(host.capi.lib().hc_profile_read(k.encode(), C.byref(m2), C.byref(n2)))
         prof[k] = {"ms_total": m2.value, "launches": n2.value}
@@ -217,10 +218,10 @@ def main():
         # passes, FETCH doubled per the gfx950 note): measured offline on exactly this workload and committed under
         # profiles/; reported only when the run matches the workload of that measurement
         traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "r01_e_traffic.json")
+        tf = os.path.join(ROOT, "profiles", "r01_h_traffic.json")
         if os.path.exists(tf) and (args.nx, args.ny, args.nz) == (256, 256, 256) and not args.fluid_only and abs(args.hematocrit - 0.10) < 1e-12:
             tj = json.load(open(tf))
-            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01_g_traffic.json (rocprofv3 --pmc, %.1f B/node)" % tj["hbm_bytes_per_node"]
+            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01_h_traffic.json (rocprofv3 --pmc, %.1f B/node)" % tj["hbm_bytes_per_node"]
         out = {
             "metric": "MLUPS + cell-vertex updates/s, 256^3 pipeflow 10% Hct",
             "value": mlups, "unit": "MLUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -239,6 +240,12 @@ def main():
                          "bytes_per_node": bytes_per_node, "nodes_per_launch": launch_nodes, "avg_launch_ms": avg_ms,
                          "launches": n.value, "peak_source": "MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)"},
             "kernel_ms": prof,
+            # the same kernel over the launches that had the GPU to themselves (velocity-update steps); the others share
+            # it with advance + spread of the next iteration on the side stream, which stretches both
+            "roofline_alone": ({"avg_launch_ms": prof["collide_stream_alone"]["ms_total"] / prof["collide_stream_alone"]["launches"] * (n.value / args.steps),
+                                "launches": prof["collide_stream_alone"]["launches"],
+                                "frac": launch_nodes * bytes_per_node / (prof["collide_stream_alone"]["ms_total"] / prof["collide_stream_alone"]["launches"] * (n.value / args.steps) * 1e-3) / 8.0e12}
+                               if prof["collide_stream_alone"]["launches"] else None),
             # whole job against the HBM roofline of the whole step: MLUPS x algorithmic bytes per node update over the
             # aggregate 8 TB/s of the GPUs used (north_star: >= 0.60 on the 512^3 pipe at 1 GPU)
             "whole_step_hbm_frac": mlups * 1e6 * bytes_per_node / (8.0e12 * world),

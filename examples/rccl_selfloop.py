@@ -82,7 +82,9 @@ comm = X.NeighbourComm(0, 1, True)
 assert comm.backend == "nccl" and comm.lo == 0 and comm.hi == 0
 proto = X.SlabProtocol(eng, comm, 5, n, True)
 proto.prepare()
-proto.run(20); t_rccl = timeit(lambda k: proto.run(k), steps)
+proto.run(20); proto.stats["merge_host_s"] = 0.0
+t_rccl = timeit(lambda k: proto.run(k), steps)
+t_merge = proto.stats["merge_host_s"] / (steps / 5) * 1e3
 proto.halo_exchange_begin(2)()
 f_two = L2.populations(); p_two = h2.cellfields.positions
 fluid = mask.reshape(-1) == 0
@@ -90,7 +92,7 @@ err_f = np.abs(f_two.reshape(-1, 19)[fluid] - f_ref.reshape(-1, 19)[fluid]).max(
 err_p = np.abs(p_two - p_ref).max()
 print("RCCL self-loop, %d^3 pipe, %d cells, %d steps: hc_iterate %.4f ms/step, slab protocol over RCCL %.4f ms/step (%+.1f %%)"
       % (n, len(centres), steps + 20, t_iter, t_rccl, (t_rccl / t_iter - 1) * 100))
-print("max |df| = %.3e   max |dx| = %.3e lu" % (err_f, err_p), flush=True)
+print("max |df| = %.3e   max |dx| = %.3e lu;  host time of one envelope merge %.3f ms, %d cells sent" % (err_f, err_p, t_merge, proto.stats["cells_sent"]), flush=True)
 assert err_f <= 1e-10 and err_p <= 1e-8, (err_f, err_p)
 # where the difference comes from: without the envelope sync, and without any particle update at all
 real_sync = proto.sync_cells_begin, proto.sync_cells_finish

@@ -42,6 +42,7 @@ SIGNATURES = {
     "hc_fork": (C.c_int, []),
     "hc_route": (C.c_int, [C.c_int]),
     "hc_join": (C.c_int, []),
+    "hc_side_stream": (C.c_int, [C.POINTER(VP)]),
     "hc_set_overlap": (C.c_int, [C.c_int]),
     "hc_profile_enable": (C.c_int, [C.c_int]),
     "hc_profile_read": (C.c_int, [C.c_char_p, c_double_p, c_long_p]),

@@ -16,6 +16,7 @@ hipStream_t stream();
 int fork();
 void route(int side);
 int join();
+bool forked();   // between fork() and join()
 
 #define HC_HIP(call)                                                         \
   do {                                                                       \
@@ -32,7 +33,7 @@ int join();
   } while (0)
 
 // per-kernel hipEvent timing (hc_profile_*)
-enum ProfKernel { PK_COLLIDE = 0, PK_SPREAD, PK_INTERP, PK_ADVANCE, PK_MECH, PK_COUNT };
+enum ProfKernel { PK_COLLIDE = 0, PK_SPREAD, PK_INTERP, PK_ADVANCE, PK_MECH, PK_COLLIDE_BESIDE, PK_COUNT };   // _BESIDE: collide launches with side-stream work next to them
 struct ProfScope {
   int k; bool on;
   hipEvent_t a, b;

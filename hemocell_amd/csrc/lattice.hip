@@ -582,7 +582,7 @@ int hcl_collide_stream_part(hc_lattice *L, int part) {
   HC_REQUIRE(L, "hcl_collide_stream_part: null lattice");
   HC_REQUIRE(part >= 0 && part <= 4, "hcl_collide_stream_part: part must be 0..4");
   HC_REQUIRE(part < 3 || L->nx >= 4, "hcl_collide_stream_part: parts 3 and 4 need a slab of at least 4 planes");
-  hc::ProfScope prof(hc::PK_COLLIDE);
+  hc::ProfScope prof(hc::forked() ? hc::PK_COLLIDE_BESIDE : hc::PK_COLLIDE);
   int rc = HC_OK;
   if (part == 0) rc = launch_collide(L, 0, L->nx);
   else if (part == 1) rc = launch_collide(L, 1, L->nx - 2);

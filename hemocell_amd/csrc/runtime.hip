@@ -11,7 +11,7 @@ static hipStream_t g_own_stream = nullptr;
 static hipStream_t g_stream = nullptr;       // main stream (own, or the caller's through hc_set_stream)
 static hipStream_t g_side = nullptr;         // side stream of fork / join
 static hipEvent_t g_fork_ev = nullptr, g_join_ev = nullptr;
-static bool g_on_side = false;
+static bool g_on_side = false, g_forked = false;
 static bool g_initialised = false;
 static bool g_profile = false;
 
@@ -29,11 +29,13 @@ hipStream_t stream() { return g_on_side ? g_side : g_stream; }
 int fork() {
   HC_HIP(hipEventRecord(g_fork_ev, g_stream));
   HC_HIP(hipStreamWaitEvent(g_side, g_fork_ev, 0));
+  g_forked = true;
   return HC_OK;
 }
+bool forked() { return g_forked; }
 void route(int side) { g_on_side = side != 0; }
 int join() {
-  g_on_side = false;
+  g_on_side = false; g_forked = false;
   HC_HIP(hipEventRecord(g_join_ev, g_side));
   HC_HIP(hipStreamWaitEvent(g_stream, g_join_ev, 0));
   return HC_OK;
@@ -108,7 +110,12 @@ int hc_init(int device) {
   if (!hc::g_own_stream) HC_HIP(hipStreamCreateWithFlags(&hc::g_own_stream, hipStreamNonBlocking));
   if (!hc::g_stream) hc::g_stream = hc::g_own_stream;
   if (!hc::g_side) {
-    HC_HIP(hipStreamCreateWithFlags(&hc::g_side, hipStreamNonBlocking));
+    // The side stream must not share a hardware queue with the main stream, or its kernels queue up behind the collide
+    // they are meant to run beside (seen with rocprofv3: two default-priority streams of this library landed on the same
+    // queue).  Streams of different priority never share one, so the side stream is created with the highest priority.
+    int lo = 0, hi = 0;
+    HC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HC_HIP(hipStreamCreateWithPriority(&hc::g_side, hipStreamNonBlocking, hi));
     HC_HIP(hipEventCreateWithFlags(&hc::g_fork_ev, hipEventDisableTiming));
     HC_HIP(hipEventCreateWithFlags(&hc::g_join_ev, hipEventDisableTiming));
   }
@@ -130,6 +137,12 @@ int hc_synchronize(void) {
 int hc_fork(void) { return hc::fork(); }
 int hc_route(int side) { hc::route(side); return HC_OK; }
 int hc_join(void) { return hc::join(); }
+int hc_side_stream(void **hip_stream) {
+  HC_REQUIRE(hip_stream, "hc_side_stream: null pointer");
+  HC_REQUIRE(hc::g_side, "hc_side_stream: hc_init() has not been called");
+  *hip_stream = (void *)hc::g_side;
+  return HC_OK;
+}
 
 int hc_profile_enable(int on) { hc::g_profile = on != 0; return HC_OK; }
 int hc_profile_reset(void) {
@@ -139,8 +152,13 @@ int hc_profile_reset(void) {
 }
 int hc_profile_read(const char *kernel, double *total_ms, long *launches) {
   HC_REQUIRE(kernel && total_ms && launches, "hc_profile_read: null pointer");
-  static const char *names[hc::PK_COUNT] = {"collide_stream", "ibm_spread", "ibm_interpolate", "advance", "mechanics"};
+  static const char *names[hc::PK_COUNT] = {"collide_stream_alone", "ibm_spread", "ibm_interpolate", "advance", "mechanics", "collide_stream_beside"};
   hc::prof_collect();
+  if (std::strcmp(kernel, "collide_stream") == 0) {   // every launch of the collide kernel
+    *total_ms = hc::g_prof_ms[hc::PK_COLLIDE] + hc::g_prof_ms[hc::PK_COLLIDE_BESIDE];
+    *launches = hc::g_prof_n[hc::PK_COLLIDE] + hc::g_prof_n[hc::PK_COLLIDE_BESIDE];
+    return HC_OK;
+  }
   for (int k = 0; k < hc::PK_COUNT; k++)
     if (std::strcmp(kernel, names[k]) == 0) { *total_ms = hc::g_prof_ms[k]; *launches = hc::g_prof_n[k]; return HC_OK; }
   hc::set_error(std::string("hc_profile_read: unknown kernel ") + kernel);

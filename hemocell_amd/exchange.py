@@ -14,6 +14,7 @@ written against a small engine interface so that it runs unchanged on the HIP en
 numpy stand-in used by the CPU gloo tests of the protocol itself.
 """
 import ctypes as C
+import time
 
 import numpy as np
 import torch
@@ -72,6 +73,25 @@ class NeighbourComm:
         return wait
 
 
+class _SideStream:
+    def __init__(self, engine):
+        self.e = engine
+        if engine._side is None:
+            p = C.c_void_p()
+            host.check(engine.lib.hc_side_stream(C.byref(p)))
+            engine._side = torch.cuda.ExternalStream(p.value, device=engine.device)
+        self.ctx = torch.cuda.stream(engine._side)
+
+    def __enter__(self):
+        self.e.route(1)
+        self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        self.ctx.__exit__(*exc)
+        self.e.route(0)
+        return False
+
+
 class HipEngine:
     """the product engine: every method is one call into libhemocell_amd.so"""
 
@@ -80,6 +100,7 @@ class HipEngine:
         self.lib = host.capi.lib()
         self.nx, self.x0, self.nx_global = lattice.nx, lattice.x0, lattice.nx_global
         self._ext_pending = set()
+        self._side = None
 
     # ---- fluid
     def halo_buffer(self, width):
@@ -105,6 +126,10 @@ class HipEngine:
 
     def join(self):
         host.check(self.lib.hc_join())
+
+    def side(self):
+        """context: the launches of the library AND torch's own work (copies, RCCL transfers) go to the library's side stream"""
+        return _SideStream(self)
 
     # ---- cells
     def n_types(self):
@@ -205,7 +230,7 @@ class SlabProtocol:
         self._hdr = {}
         self._pending = None     # completion of a face exchange in flight
         self._spread_done = False   # the spread of the coming iteration already ran beside the last collide
-        self.stats = {"cells_sent": 0, "cells_new": 0, "cells_dropped": 0}
+        self.stats = {"cells_sent": 0, "cells_new": 0, "cells_dropped": 0, "merge_host_s": 0.0}
 
     # ------------------------------------------------------------------ fluid halos
     def _bufs(self, width):
@@ -306,6 +331,7 @@ class SlabProtocol:
             hdr = self._header_buffers(t)
             if ready is not None:
                 ready.synchronize()
+            t_host = time.perf_counter()
             hr = [hdr[0][3].numpy() if comm.lo is not None else np.zeros(1, np.int64),
                   hdr[1][3].numpy() if comm.hi is not None else np.zeros(1, np.int64)]
             n_lo, n_hi = int(hr[0][0]), int(hr[1][0])
@@ -347,6 +373,7 @@ class SlabProtocol:
             if len(drop):
                 e.remove_cells(t, drop)
                 self.stats["cells_dropped"] += len(drop)
+            self.stats["merge_host_s"] += time.perf_counter() - t_host   # host time while the GPU still interpolates
 
     def _dev(self):
         return getattr(self.e, "device", "cpu")
@@ -364,12 +391,13 @@ class SlabProtocol:
             self.halo_fresh = True
 
     def step(self, more=False):
-        """No transfer is waited for while there is independent work left: the 5 crossing populations of a face leave
-        right after the collide that produced them and travel during advance, mechanics, the next spread and the next
-        interior collide; the wider message an interpolation needs leaves as soon as the two planes next to each face
-        are collided and travels during the interior collide of the same step.  Between two velocity updates advance,
-        mechanics and the spread of the NEXT iteration do not depend on the collide: with more=True (another step
-        follows in the same run) they are put on the library's side stream beside it, as hc_iterate does."""
+        """Nothing on the main stream ever waits for a transfer.  Between two velocity updates the main stream only
+        collides the interior planes; beside it, on the library's side stream: the arrival of the neighbours' faces, the
+        collide of the two face planes, the packing and departure of the 5 crossing populations for the next step, then
+        advance, mechanics and (with more=True: another step follows in the same run) the repulsion and spread of the
+        NEXT iteration, none of which depend on the collide.  On a velocity update the wider message an interpolation
+        needs leaves as soon as the two planes next to each face are collided and travels during the interior collide;
+        the id headers of the envelope sync travel and land on the host while the velocities are interpolated."""
         e = self.e
         it = self.iter
         particle_step = it % self.k_p == 0
@@ -379,16 +407,16 @@ class SlabProtocol:
             e.repulsion(it)                                   # core/hemoCell.cpp:307-312
             e.spread()                                        # :313
         self._spread_done = False
-        beside = self.overlap and more and not particle_step
-        if beside:
-            e.fork()
-        if not self.overlap:                                  # :317
+        if not self.overlap:                                  # :317, strictly one stream, nothing in flight across phases
             if not self.halo_fresh:
                 self.halo_exchange_begin(1)()
             e.collide(0)
             e.step_end()
             if particle_step:
                 self.halo_exchange_begin(2)()
+                self.sync_cells_finish(self.sync_cells_begin_after(e.interpolate))
+            e.advance()                                       # :342
+            e.mechanics(it)                                   # :345
         elif particle_step:
             self.halo_drain()
             e.collide(4)                                      # the two planes next to each face first ...
@@ -396,31 +424,32 @@ class SlabProtocol:
             e.collide(3)
             e.step_end()
             finish()
+            self.sync_cells_finish(self.sync_cells_begin_after(e.interpolate))   # :327-332
+            e.advance()
+            e.mechanics(it)
         else:
-            if self.halo_fresh:
-                e.collide(0)
-            else:
-                e.collide(1)                                  # interior planes while the faces are in flight
-                self.halo_drain()
+            e.fork()
+            e.collide(1)                                      # main stream: interior planes
+            with e.side():
+                self.halo_drain()                             # faces of the neighbours (already here after a velocity update)
                 e.collide(2)
+                self._pending = self.halo_exchange_begin(1, next=True)   # my faces of the state being written
             e.step_end()
-        self.halo_fresh = particle_step
-        if particle_step:                                     # :327-332
-            plans = self.sync_cells_begin()                   # id headers travel and land on the host ...
-            e.interpolate()                                   # ... while velocities are interpolated (at halo nodes too)
-            self.sync_cells_finish(plans)
-        elif self.overlap:
-            self._pending = self.halo_exchange_begin(1)       # faces of the state just written, needed by the next collide
-        if beside:
-            e.route(1)
-        e.advance()                                           # :342
-        e.mechanics(it)                                       # :345
-        if beside:
-            e.repulsion(it + 1)
-            e.spread()                                        # :313 of iteration it + 1
+            with e.side():
+                e.advance()
+                e.mechanics(it)
+                if more:
+                    e.repulsion(it + 1)
+                    e.spread()                                # :313 of iteration it + 1
+                    self._spread_done = True
             e.join()
-            self._spread_done = True
+        self.halo_fresh = particle_step
         self.iter = it + 1
+
+    def sync_cells_begin_after(self, interpolate):
+        plans = self.sync_cells_begin()                       # id headers travel and land on the host ...
+        interpolate()                                         # ... while velocities are interpolated (at halo nodes too)
+        return plans
 
     def run(self, n):
         for k in range(n):

@@ -52,11 +52,12 @@ int hc_synchronize(void);
 int hc_fork(void);
 int hc_route(int side);
 int hc_join(void);
+int hc_side_stream(void **hip_stream);  /* the side stream's hipStream_t, for a host framework that has to enqueue its own work (transfers) there */
 /* hc_iterate overlaps those phases by itself (default); 0 = strictly one stream (A/B measurements) */
 int hc_set_overlap(int on);
 /* per-launch hipEvent timing of the dominant kernel (helper/profiler.h:46-77 "collideAndStream" timer) */
 int hc_profile_enable(int on);
-int hc_profile_read(const char *kernel, double *total_ms, long *launches); /* "collide_stream", "ibm_spread", "ibm_interpolate", "advance", "mechanics" */
+int hc_profile_read(const char *kernel, double *total_ms, long *launches); /* "collide_stream" (every launch) = "collide_stream_alone" + "collide_stream_beside" (launches with advance / spread on the side stream next to them), "ibm_spread", "ibm_interpolate", "advance", "mechanics" */
 int hc_profile_reset(void);
 /* A/B switch: 1 = per-vertex IBM kernels with direct global atomics instead of the LDS-tiled per-cell kernels */
 int hc_debug_ibm_per_vertex(int on);

@@ -1,0 +1,48 @@
+"""python profiles/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [skip_launches]
+
+HBM traffic per launch of the kernels of bench.py from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
+counter values are KiB per dispatch).  gfx950 correction as prescribed in MI355X_MICROARCH.md (HBM section) and
+calibrated in profiles/r01_pmc_collide_traffic.md: FETCH_SIZE reports half of the bytes of a streamed read (x2),
+WRITE_SIZE is exact."""
+import csv
+import json
+import sys
+
+NODES = 256 ** 3
+
+
+def per_kernel(path, counter, skip):
+    acc = {}
+    for row in csv.DictReader(open(path)):
+        if row["Counter_Name"] != counter:
+            continue
+        name = row["Kernel_Name"].split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "").strip()
+        if "anonymous" in row["Kernel_Name"] and not name:
+            name = row["Kernel_Name"].split("::")[1].split("(")[0]
+        acc.setdefault(name, []).append(float(row["Counter_Value"]))
+    return {k: sum(v[skip:]) / max(1, len(v[skip:])) for k, v in acc.items() if len(v) > skip}
+
+
+def main():
+    skip = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE", skip)
+    write = per_kernel(sys.argv[2], "WRITE_SIZE", skip)
+    key = [k for k in fetch if "collide_stream_kernel" in k][0]
+    total = fetch[key] * 1024 * 2 + write[key] * 1024
+    out = {
+        "kernel": "collide_stream_kernel",
+        "workload": "pipe 256x256x256, R=127, 1937 RBC (bench.py default)",
+        "nodes": NODES,
+        "FETCH_SIZE_KiB_avg": fetch[key], "WRITE_SIZE_KiB_avg": write[key],
+        "correction": "gfx950: FETCH_SIZE counts 1/2 of streamed read bytes (MI355X_MICROARCH.md, HBM section) -> x2; WRITE_SIZE exact; "
+                      "calibrated on the all-fluid box (177/176 B per node, profiles/r01_pmc_collide_traffic.md)",
+        "hbm_bytes_per_launch": total, "hbm_bytes_per_node": total / NODES,
+        "other_kernels_KiB": {k: {"FETCH_SIZE": fetch[k], "WRITE_SIZE": write.get(k)} for k in fetch
+                              if k != key and ("ibm_" in k or "advance" in k or "mechanics" in k)},
+    }
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

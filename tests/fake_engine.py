@@ -60,6 +60,10 @@ class FakeEngine:
     def join(self):
         pass
 
+    def side(self):
+        import contextlib
+        return contextlib.nullcontext()
+
     def post_stream(self):
         """S(x,q) = P(x - c_q, q) on the bulk planes"""
         fin = self.f[self.cur]

@@ -230,6 +230,7 @@ class SlabProtocol:
         self._hdr = {}
         self._pending = None     # completion of a face exchange in flight
         self._spread_done = False   # the spread of the coming iteration already ran beside the last collide
+        self._planned = False       # the cell extents for the coming envelope sync are already on their way to the host
         self.stats = {"cells_sent": 0, "cells_new": 0, "cells_dropped": 0, "merge_host_s": 0.0}
 
     # ------------------------------------------------------------------ fluid halos
@@ -401,7 +402,7 @@ class SlabProtocol:
         e = self.e
         it = self.iter
         particle_step = it % self.k_p == 0
-        if particle_step:
+        if particle_step and not self._planned:
             self.plan_cells()                                 # extents for the envelope sync at the end of this step
         if not self._spread_done:
             e.repulsion(it)                                   # core/hemoCell.cpp:307-312
@@ -418,13 +419,18 @@ class SlabProtocol:
             e.advance()                                       # :342
             e.mechanics(it)                                   # :345
         elif particle_step:
-            self.halo_drain()
+            e.fork()
+            with e.side():
+                plans = self.sync_cells_begin()               # which cells cross + id headers: needs positions only, so it
+            self.halo_drain()                                 # travels and lands on the host beside the collide
             e.collide(4)                                      # the two planes next to each face first ...
             finish = self.halo_exchange_begin(2, next=True)   # ... so that they travel while the interior is collided
             e.collide(3)
             e.step_end()
             finish()
-            self.sync_cells_finish(self.sync_cells_begin_after(e.interpolate))   # :327-332
+            e.join()
+            e.interpolate()                                   # :327-332, at halo nodes too
+            self.sync_cells_finish(plans)
             e.advance()
             e.mechanics(it)
         else:
@@ -437,12 +443,17 @@ class SlabProtocol:
             e.step_end()
             with e.side():
                 e.advance()
+                if (it + 1) % self.k_p == 0:
+                    self.plan_cells()                         # positions are final for the sync of the next step
+                    self._planned = True
                 e.mechanics(it)
                 if more:
                     e.repulsion(it + 1)
                     e.spread()                                # :313 of iteration it + 1
                     self._spread_done = True
             e.join()
+        if particle_step:
+            self._planned = False
         self.halo_fresh = particle_step
         self.iter = it + 1
 

@@ -85,6 +85,7 @@ struct hc_lattice {
   double omega;
   size_t plane;          // ny*nz
   size_t npad;           // (nx+2*HALO)*plane
+  size_t qstride;        // doubles from population q to q+1 of the same node: npad + padding (see hcl_create)
   double *f[2];          // [19][npad] post-collision populations (fBar), ping-pong
   int cur;               // f[cur] is read by the next collide
   double *force[3];      // [3][npad] IBM force accumulators, rotated: fcur -> (fcur+1)%3 every step

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void ibm_spread_kernel(LatView v, long n, cons
 // ----------------------------------------------------------------------------
 // interpolate: v = sum_j w_j * (j/rho + F/2)(node_j) on the post-stream state
 struct PopView {
-  const double *f; const double *F; double bx, by, bz;
+  const double *f; const double *F; double bx, by, bz; long qs;   // qs: population stride
 };
 
 __device__ __forceinline__ void node_velocity(const LatView &v, const PopView &pv, int lx, int ly, int lz, long node, double u[3]) {
@@ -59,7 +59,7 @@ __device__ __forceinline__ void node_velocity(const LatView &v, const PopView &p
     if (CX == 1) off += xm; else if (CX == -1) off += xp;                             \
     if (CY == 1) { off += ym; ok = ok && ymk; } else if (CY == -1) { off += yp; ok = ok && ypk; } \
     if (CZ == 1) { off += zm; ok = ok && zmk; } else if (CZ == -1) { off += zp; ok = ok && zpk; } \
-    const double fq = ok ? pv.f[(long)Q * v.npad + node + off] : 0.0;                 \
+    const double fq = ok ? pv.f[(long)Q * pv.qs + node + off] : 0.0;                 \
     r += fq;                                                                          \
     if (CX == 1) jx += fq; else if (CX == -1) jx += -fq;                              \
     if (CY == 1) jy += fq; else if (CY == -1) jy += -fq;                              \
@@ -411,7 +411,7 @@ int hcp_interpolate(hc_cells *C) {
   const hc_lattice *L = C->L;
   const LatView v = make_view(L);
   // state after hcl_step_end: f[cur] holds the populations just written, force[(fcur+2)%3] the force they were collided with
-  PopView pv{L->f[L->cur], L->force[(L->fcur + 2) % 3], L->body[0], L->body[1], L->body[2]};
+  PopView pv{L->f[L->cur], L->force[(L->fcur + 2) % 3], L->body[0], L->body[1], L->body[2], (long)L->qstride};
   for (int t = 0; t < C->ntypes; t++) {
     const long n = C->ncells[t] * C->types[t]->host.nv, f = C->first[t];
     if (n == 0) continue;

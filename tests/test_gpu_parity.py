@@ -277,10 +277,12 @@ def test_ibm_oversized_cells_take_the_fallback_paths(orc, gpu, scale, which):
     Lo.destroy(); Lg.destroy()
 
 
-@pytest.mark.parametrize("case", ["pipe_rbc", "pipe_rbc_plt_cadence", "box_periodic"])
+@pytest.mark.parametrize("case", ["pipe_rbc", "pipe_rbc_plt_cadence", "box_periodic", "pipe_rbc_plt_cadence_beside"])
 def test_iterate_trajectories_vs_oracle(orc, gpu, case):
     """HemoCell::iterate for N steps: fluid populations and vertex positions within 1e-6 relative of the
-    oracle (north_star tolerance); in practice ~1e-12 (only the atomic spread order differs)"""
+    oracle (north_star tolerance); in practice ~1e-12 (only the atomic spread order differs).
+    _beside: no deletion checks inside the call, so that hc_iterate puts advance, mechanics and the next spread on
+    the side stream beside the collide between velocity updates (the schedule bench.py measures)"""
     if case == "box_periodic":
         nx, ny, nz = 32, 32, 32
         periodic = (1, 1, 1); mask = np.zeros((nx, ny, nz), np.uint8); k_m, k_p, plt = 1, 1, False
@@ -288,7 +290,7 @@ def test_iterate_trajectories_vs_oracle(orc, gpu, case):
     else:
         nx, ny, nz = 48, 34, 34
         mask, R = gpu.pipe_mask(nx, ny, nz); periodic = (1, 0, 0)
-        plt = case.endswith("cadence"); k_m, k_p = (4, 2) if plt else (1, 1)
+        plt = "cadence" in case; k_m, k_p = ((6, 3) if case.endswith("beside") else (4, 2)) if plt else (1, 1)
         F = (5e-6, 0, 0)
     Po, Lo, Lg, So, hg = _sim_pair(orc, gpu, nx, ny, nz, periodic, mask, plt=plt, k_m=k_m, k_p=k_p)
     assert _add_both(orc, So, hg, 0, (10.0, 16.5, 16.5), (90, 0, 0))
@@ -303,7 +305,17 @@ def test_iterate_trajectories_vs_oracle(orc, gpu, case):
     nsteps = 60
     for _ in range(nsteps):
         orc.orc_sim_iterate(So)
+    lib = gpu.capi.lib()
+    if case.endswith("beside"):
+        hg.deletion_check_every = 10 ** 6
+        gpu.check(lib.hc_profile_reset()); gpu.check(lib.hc_profile_enable(1))
     hg.iterate(nsteps)
+    if case.endswith("beside"):
+        import ctypes as C
+        ms, n = C.c_double(), C.c_long()
+        gpu.check(lib.hc_profile_enable(0))
+        gpu.check(lib.hc_profile_read(b"collide_stream_beside", C.byref(ms), C.byref(n)))
+        assert n.value == nsteps - nsteps // k_p - 1   # every step without a velocity update except the last of the call
     p_o, v_o, f_o = _oracle_state(orc, So)
     p_g = hg.cellfields.positions
     assert hg.iter == So.contents.iter == nsteps

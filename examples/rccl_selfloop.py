@@ -94,11 +94,7 @@ print("RCCL self-loop, %d^3 pipe, %d cells, %d steps: hc_iterate %.4f ms/step, s
       % (n, len(centres), steps + 20, t_iter, t_rccl, (t_rccl / t_iter - 1) * 100))
 print("max |df| = %.3e   max |dx| = %.3e lu;  host time of one envelope merge %.3f ms, %d cells sent" % (err_f, err_p, t_merge, proto.stats["cells_sent"]), flush=True)
 assert err_f <= 1e-10 and err_p <= 1e-8, (err_f, err_p)
-# where the difference comes from: without the envelope sync, and without any particle update at all
-real_sync = proto.sync_cells_begin, proto.sync_cells_finish
-proto.sync_cells_begin, proto.sync_cells_finish = (lambda: None), (lambda plans: None)
-proto.run(10); t_nosync = timeit(lambda k: proto.run(k), steps)
-proto.sync_cells_begin, proto.sync_cells_finish = real_sync
+# where the difference comes from: without any particle update, and with a plain copy as the transport
 proto.k_p = 10**9
 proto.run(10); t_nop = timeit(lambda k: proto.run(k), steps)
 t_issue = issue_time(lambda k: proto.run(k), steps)
@@ -112,6 +108,6 @@ proto.k_p = 5
 proto.run(10); t_loop = timeit(lambda k: proto.run(k), steps)
 print("hc_iterate        : %.4f (k_p=5)  %.4f (no particle update)" % (t_iter, t_iter_nop))
 print("protocol, loopback: %.4f (k_p=5)  %.4f (face messages only; host issue time %.4f)" % (t_loop, t_nop_loop, t_issue_loop))
-print("protocol over RCCL: %.4f (k_p=5)  %.4f (k_p=5, sync_cells skipped)  %.4f (face messages only; host issue time %.4f)  %.4f (face messages only, not overlapped)"
-      % (t_rccl, t_nosync, t_nop, t_issue, t_nop_serial), flush=True)
+print("protocol over RCCL: %.4f (k_p=5)  %.4f (face messages only; host issue time %.4f)  %.4f (face messages only, one stream, nothing in flight across phases)"
+      % (t_rccl, t_nop, t_issue, t_nop_serial), flush=True)
 dist.destroy_process_group()

@@ -96,6 +96,7 @@ SIGNATURES = {
     "hcp_boundary_repulsion": (C.c_int, [VP]),
     "hcp_spread": (C.c_int, [VP, C.c_int]),
     "hcp_interpolate": (C.c_int, [VP]),
+    "hcp_interpolate_cells": (C.c_int, [VP, C.c_int, c_int_p, C.c_int]),
     "hcp_advance": (C.c_int, [VP, C.c_int]),
     "hcp_mechanics": (C.c_int, [VP, C.c_long, C.c_int]),
     "hcp_mechanics_components": (C.c_int, [VP, C.c_int, c_double_p]),

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv,
 }
 
 __global__ __launch_bounds__(256) void ibm_interpolate_cell_kernel(LatView v, PopView pv, int nv, const double *px, const double *py,
-                                                                   const double *pz, double *vx, double *vy, double *vz) {
+                                                                   const double *pz, double *vx, double *vy, double *vz, const int *slots) {
   // 54 KB in all, so that three workgroups share a CU: 16-bit slots, and the node list reuses the mask tile
   // (the mask is only read while the stencils are formed)
   constexpr unsigned short FREE = 0xFFFF, MARK = 0xFFFE;
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void ibm_interpolate_cell_kernel(LatView v, Po
   __shared__ double ux[NODE_CAP], uy[NODE_CAP], uz[NODE_CAP];
   __shared__ int s_red[6 * MAXW], s_count;
   const int tid = threadIdx.x, nth = blockDim.x;
-  const long base = (long)blockIdx.x * nv;
+  const long base = (long)(slots ? slots[blockIdx.x] : (int)blockIdx.x) * nv;   // slots: only the listed cells of the type
   Tile t; VStencil vs[NVPT];
   bool tiled = cell_prologue(v, nv, base, px, py, pz, s_red, mt, t, vs);
   const int sy = t.e[2], sx = t.e[1] * t.e[2];
@@ -423,9 +423,30 @@ int hcp_interpolate(hc_cells *C) {
     else
       hipLaunchKernelGGL(ibm_interpolate_cell_kernel, dim3((unsigned)C->ncells[t]), dim3(nv > 128 ? 256 : 128), 0, hc::stream(), v, pv, nv,
                          (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
-                         C->vel[0] + f, C->vel[1] + f, C->vel[2] + f);
+                         C->vel[0] + f, C->vel[1] + f, C->vel[2] + f, (const int *)nullptr);
     HC_HIP(hipGetLastError());
   }
+  return HC_OK;
+}
+
+int hcp_interpolate_cells(hc_cells *C, int type, const int *slots, int n) {
+  HC_REQUIRE(C && type >= 0 && type < C->ntypes && n >= 0, "hcp_interpolate_cells: bad arguments");
+  if (n == 0) return HC_OK;
+  HC_REQUIRE(slots, "hcp_interpolate_cells: null pointer");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  for (int i = 0; i < n; i++) HC_REQUIRE(slots[i] >= 0 && slots[i] < C->ncells[type], "hcp_interpolate_cells: slot out of range");
+  int *d_slots = nullptr;
+  rc = stage_ints(C, 1, &d_slots, slots, n); if (rc != HC_OK) return rc;
+  hc::ProfScope prof(hc::PK_INTERP);
+  const hc_lattice *L = C->L;
+  const LatView v = make_view(L);
+  PopView pv{L->f[L->cur], L->force[(L->fcur + 2) % 3], L->body[0], L->body[1], L->body[2], (long)L->qstride};
+  const long f = C->first[type];
+  const int nv = C->types[type]->host.nv;
+  hipLaunchKernelGGL(ibm_interpolate_cell_kernel, dim3((unsigned)n), dim3(nv > 128 ? 256 : 128), 0, hc::stream(), v, pv, nv,
+                     (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
+                     C->vel[0] + f, C->vel[1] + f, C->vel[2] + f, (const int *)d_slots);
+  HC_HIP(hipGetLastError());
   return HC_OK;
 }
 

@@ -200,6 +200,10 @@ class HipEngine:
         if self.C is not None:
             self.C.interpolateFluidVelocity()
 
+    def interpolate_cells(self, t, slots):
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        host.check(self.lib.hcp_interpolate_cells(self.C.ptr, t, slots.ctypes.data_as(host.capi.c_int_p), len(slots)))
+
     def advance(self):
         if self.C is not None:
             self.C.advanceParticles(False)
@@ -325,24 +329,42 @@ class SlabProtocol:
         return plans
 
     def sync_cells_finish(self, plans):
-        """second half: records of the crossing cells (they carry the velocities just interpolated), merge, drop"""
+        self.sync_cells_merge(self.sync_cells_records_begin(plans, False))
+
+    def sync_cells_records_begin(self, plans, interpolate_first):
+        """second part: the records of the crossing cells start to travel.  They carry interpolated velocities, so with
+        interpolate_first the crossing cells are interpolated here, ahead of the rest: the caller launches the
+        interpolation of all cells afterwards (same values for these) and the transfer hides beside it."""
         e, comm = self.e, self.comm
+        out = []
         for t, ext, ids, send, ready in plans:
-            n = len(ids)
             hdr = self._header_buffers(t)
             if ready is not None:
                 ready.synchronize()
-            t_host = time.perf_counter()
             hr = [hdr[0][3].numpy() if comm.lo is not None else np.zeros(1, np.int64),
                   hdr[1][3].numpy() if comm.hi is not None else np.zeros(1, np.int64)]
             n_lo, n_hi = int(hr[0][0]), int(hr[1][0])
             ids_r = [hr[0][1:1 + n_lo].copy(), hr[1][1:1 + n_hi].copy()]
-            # phase 2: records
+            if interpolate_first:
+                both = np.union1d(send[0][0], send[1][0]).astype(np.int32)
+                if len(both):
+                    e.interpolate_cells(t, both)
             shift_lo = float(self.nx_global) if (self.periodic_x and comm.rank == 0) else 0.0          # crossing the seam downward
             shift_hi = -float(self.nx_global) if (self.periodic_x and comm.rank == comm.world - 1) else 0.0
             rec_s = [e.pack_cells(t, send[0][0], shift_lo), e.pack_cells(t, send[1][0], shift_hi)]
             rec_r = [e.record_buffer(t, n_lo), e.record_buffer(t, n_hi)]
-            comm.exchange(rec_s[0], rec_s[1], rec_r[0], rec_r[1])()
+            wait = comm.exchange(rec_s[0], rec_s[1], rec_r[0], rec_r[1])
+            out.append((t, ext, ids, send, ids_r, rec_s, rec_r, wait))
+        return out
+
+    def sync_cells_merge(self, states):
+        """last part: wait for the records, merge them (a local vertex wins), drop copies nobody refreshed"""
+        e = self.e
+        for t, ext, ids, send, ids_r, rec_s, rec_r, wait in states:
+            n = len(ids)
+            n_lo, n_hi = len(ids_r[0]), len(ids_r[1])
+            wait()
+            t_host = time.perf_counter()
             self.stats["cells_sent"] += len(send[0][0]) + len(send[1][0])
             # phase 3: merge.  Incoming ids are looked up in the local ids (sorted search); unknown ones are appended
             # in arrival order, and a cell that arrives from both sides (world == 2) is new only the first time
@@ -429,8 +451,9 @@ class SlabProtocol:
             e.step_end()
             finish()
             e.join()
-            e.interpolate()                                   # :327-332, at halo nodes too
-            self.sync_cells_finish(plans)
+            states = self.sync_cells_records_begin(plans, True)   # crossing cells interpolated first, their records leave
+            e.interpolate()                                   # :327-332, all cells, at halo nodes too
+            self.sync_cells_merge(states)
             e.advance()
             e.mechanics(it)
         else:

@@ -203,6 +203,9 @@ int hcp_boundary_repulsion(hc_cells *C);
 int hcp_spread(hc_cells *C, int force_limit);
 /* cellfields->interpolateFluidVelocity() (core/hemoCell.cpp:329 -> core/hemoCellParticleField.cpp:819-839) */
 int hcp_interpolate(hc_cells *C);
+/* the same for the listed cells of one type only (slab runs interpolate the cells that cross a face first, so that
+ * their records travel while the rest is interpolated) */
+int hcp_interpolate_cells(hc_cells *C, int type, const int *slots, int n);
 /* cellfields->advanceParticles() (core/hemoCell.cpp:342 -> core/hemoCellParticleField.cpp:566-588) */
 int hcp_advance(hc_cells *C, int check_deletions);
 /* cellfields->applyConstitutiveModel(forced) (core/hemoCell.cpp:345 -> core/hemoCellParticleField.cpp:633-675) */

@@ -137,6 +137,13 @@ class FakeEngine:
             v[own[s]] = (self.cell_speed[int(cid)], 0.0, 0.0)
             self.vel[s] = v
 
+    def interpolate_cells(self, t, slots):
+        own = self._owned()
+        for s in slots:
+            v = np.full((self._nv, 3), np.nan)
+            v[own[s]] = (self.cell_speed[int(self.ids[s])], 0.0, 0.0)
+            self.vel[s] = v
+
     def advance(self):
         self.pos += self.vel
 

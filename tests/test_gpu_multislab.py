@@ -117,3 +117,15 @@ def test_slabs_match_single_domain(tmp_path, gpu, world, rep):
             assert np.allclose(got[:3], want[:3], rtol=1e-6, atol=1e-18), (got, want)
     travelled = np.abs(allpos[:, 0] - _initial_x()).max()
     assert travelled > 5.0, travelled
+
+
+def test_slab_protocol_over_rccl_matches_hc_iterate(gpu):
+    """the real transport of N > 1 runs (torch.distributed backend nccl = RCCL) on the one GPU of the test box: a single
+    rank that is its own periodic neighbour sends to and receives from itself; examples/rccl_selfloop.py asserts that
+    the slab protocol then reproduces hc_iterate (own process: the process group and the stream binding stay there)"""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "rccl_selfloop.py"), "128", "30"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "max |df|" in r.stdout and "protocol over RCCL" in r.stdout

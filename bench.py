@@ -177,6 +177,10 @@ def main():
         host.capi.check(host.capi.lib().hc_synchronize())
 
     runner.run(args.warmup)
+    import gc
+    gc.collect()   # nothing of the set-up is left for a collection inside the timed region (slab runs are driven from
+    gc.freeze()    # Python: a full collection with torch loaded takes ~65 ms, during which no step is enqueued)
+    gc.disable()
     host.capi.lib().hc_profile_reset()
     host.capi.lib().hc_profile_enable(0 if args.no_kernel_profile else 1)
     barrier()
@@ -184,6 +188,7 @@ def main():
     runner.run(args.steps)
     barrier()
     t1 = time.perf_counter()
+    gc.enable()
     host.capi.lib().hc_profile_enable(0)
     elapsed = t1 - t0
     if world > 1:

@@ -107,6 +107,11 @@ def body_force(ny, nu_lbm, Re=0.5):
 
 def main():
     args = parse()
+    # stdout carries exactly one line, the JSON result: RCCL prints its version banner to stdout (and gloo its
+    # connection notes), so everything else that writes to file descriptor 1 is sent to stderr
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -257,7 +262,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

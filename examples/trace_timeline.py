@@ -14,5 +14,5 @@ busy_end = rows[skip][0]
 for start, end, stream, name, gx, gy in rows[skip:skip + count]:
     gap = (start - busy_end) / 1e3
     busy_end = max(busy_end, end)
-    short = name.split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "")[:40]
+    short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0][:40]
     print("%10.1f us  dur %8.1f  gap %7.1f  s%-2d %-40s grid %d x %d" % ((start - t0) / 1e3, (end - start) / 1e3, gap, stream, short, gx, gy))

@@ -36,6 +36,7 @@ def parse():
                     help="cases/performance_testing geometry: fully periodic box, no walls, tau = 1, body force on all axes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true", help="A/B: no per-kernel hipEvent brackets in the timed region (roofline fields are then empty)")
+    ap.add_argument("--plane-padding", choices=["auto", "on", "off"], default="auto", help="A/B: padded x-plane stride (auto: planes that are a multiple of 1 MiB)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="A/B: one stream only (by default advance, mechanics and the next spread run beside the collide between velocity updates)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -140,6 +141,7 @@ def main():
     host.init(local_rank)
     if args.no_overlap:
         host.capi.check(host.capi.lib().hc_set_overlap(0))
+    host.capi.check(host.capi.lib().hc_debug_force_plane_padding({"auto": 0, "on": 1, "off": -1}[args.plane_padding]))
 
     # examples/pipeflow/config.xml:25-28: dx 5e-7, dt 1e-7, nuP 1.1e-6 -> tau 1.82; performance_testing: dt = -1 -> tau = 1
     P = host.base_parameters(dt=-1.0) if args.periodic_box else host.base_parameters()

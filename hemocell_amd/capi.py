@@ -48,6 +48,7 @@ SIGNATURES = {
     "hc_profile_read": (C.c_int, [C.c_char_p, c_double_p, c_long_p]),
     "hc_profile_reset": (C.c_int, []),
     "hc_debug_ibm_per_vertex": (C.c_int, [C.c_int]),
+    "hc_debug_force_plane_padding": (C.c_int, [C.c_int]),
     "hcl_create": (C.c_int, [C.POINTER(VP), C.c_int, C.c_int, C.c_int, c_int_p, C.c_double, C.c_int, C.c_int, C.c_int]),
     "hcl_destroy": (C.c_int, [VP]),
     "hcl_set_mask": (C.c_int, [VP, VP]),

@@ -67,7 +67,7 @@ namespace hcc {
 // lattice view for the IBM kernels
 struct LatView {
   const uint8_t *mask;
-  int nx, ny, nz, plane; long npad;
+  int nx, ny, nz; long plane; long npad;   // plane: elements from x-plane to x-plane (hc_lattice::xs)
   int x0;                 // global x of local plane 0
   int wrap_x, halo_x;     // single periodic slab: wrap; multi slab: one halo plane is addressable
   int per_y, per_z;
@@ -77,7 +77,7 @@ struct LatView {
 
 inline LatView make_view(const hc_lattice *L) {
   LatView v;
-  v.mask = L->mask; v.nx = L->nx; v.ny = L->ny; v.nz = L->nz; v.plane = (int)L->plane; v.npad = (long)L->npad;
+  v.mask = L->mask; v.nx = L->nx; v.ny = L->ny; v.nz = L->nz; v.plane = (long)L->xs; v.npad = (long)L->npad;
   v.x0 = L->x0; v.wrap_x = (L->n_slabs == 1 && L->periodic[0]) ? 1 : 0; v.halo_x = L->n_slabs > 1 ? 1 : 0;
   v.per_y = L->periodic[1]; v.per_z = L->periodic[2]; v.nx_global = L->nx_global;
   v.dirty = L->fdirty[L->fcur]; v.epoch = L->fepoch[L->fcur];

@@ -299,7 +299,7 @@ int hcp_add_cell(hc_cells *C, int type, long cell_id, const double centre_lu[3],
     else if (lx < -HALO || lx >= L->nx + HALO) return false;
     if (ly < 0 || ly >= L->ny) { if (L->periodic[1]) ly = ((ly % L->ny) + L->ny) % L->ny; else return false; }
     if (lz < 0 || lz >= L->nz) { if (L->periodic[2]) lz = ((lz % L->nz) + L->nz) % L->nz; else return false; }
-    return mask[(size_t)(lx + HALO) * L->plane + (size_t)ly * L->nz + lz] != 0;
+    return mask[(size_t)(lx + HALO) * L->xs + (size_t)ly * L->nz + lz] != 0;
   };
   const int deny = (int)((min_dist_um * 1e-6) / C->P.dx);
   bool ok = true;

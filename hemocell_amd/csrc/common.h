@@ -83,8 +83,9 @@ struct hc_lattice {
   int periodic[3];       // global periodicity
   int x0, nx_global, n_slabs;
   double omega;
-  size_t plane;          // ny*nz
-  size_t npad;           // (nx+2*HALO)*plane
+  size_t plane;          // ny*nz nodes of one x-plane
+  size_t xs;             // elements from x-plane to x-plane: plane, or plane + 8 rows of padding (see hcl_create)
+  size_t npad;           // (nx+2*HALO)*xs
   size_t qstride;        // doubles from population q to q+1 of the same node: npad + padding (see hcl_create)
   double *f[2];          // [19][npad] post-collision populations (fBar), ping-pong
   int cur;               // f[cur] is read by the next collide

@@ -32,7 +32,8 @@ struct LatArgs {
   double *Fzero;       // IBM force to zero   [3][npad]
   const uint8_t *mask;
   int nx, ny, nz;
-  int plane;
+  int plane;             // nodes of one x-plane
+  long xs;               // elements from x-plane to x-plane (plane + padding)
   long npad;
   long qs;               // population stride (npad + padding)
   int x_begin;
@@ -54,10 +55,10 @@ struct Nbr {  // element offsets to the -1 / +1 neighbour along each axis, and v
 
 __device__ __forceinline__ Nbr neighbours(const LatArgs &a, int x, int y, int z) {
   Nbr n;
-  n.xm = -(long)a.plane; n.xp = (long)a.plane;
+  n.xm = -a.xs; n.xp = a.xs;
   if (a.wrap_x) {
-    if (x == 0) n.xm = (long)(a.nx - 1) * a.plane;
-    if (x == a.nx - 1) n.xp = -(long)(a.nx - 1) * a.plane;
+    if (x == 0) n.xm = (long)(a.nx - 1) * a.xs;
+    if (x == a.nx - 1) n.xp = -(long)(a.nx - 1) * a.xs;
   }
   n.ym = -a.nz; n.yp = a.nz; n.ym_ok = n.yp_ok = true;
   if (y == 0) { if (a.per_y) n.ym = (a.ny - 1) * a.nz; else n.ym_ok = false; }
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void collide_stream_kernel(LatArgs a) {
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (cum[mid] <= t) lo = mid; else hi = mid - 1; }
   const int y = lo, z = a.row_z0[(long)xp * a.ny + y] + (t - cum[y]);
   const int p = y * a.nz + z;
-  const long node = (long)(x + HALO) * a.plane + p;
+  const long node = (long)(x + HALO) * a.xs + p;
   const uint8_t m = a.mask[node];
   if (m == 2) return;   // solid node with no fluid neighbour: inert under full-way bounce-back
   const Nbr n = neighbours(a, x, y, z);
@@ -220,7 +221,7 @@ __global__ void init_eq_kernel(LatArgs a, double rhoBar, double j0, double j1, d
   if (p >= a.plane) return;
   const int x = a.x_begin + blockIdx.y;
   const int y = p / a.nz, z = p - y * a.nz;
-  const long node = (long)(x + HALO) * a.plane + p;
+  const long node = (long)(x + HALO) * a.xs + p;
   const Nbr n = neighbours(a, x, y, z);
   const double invRho = 1.0 / (1.0 + rhoBar);
   const double jSqr = j0 * j0 + j1 * j1 + j2 * j2;
@@ -244,7 +245,7 @@ __global__ void download_kernel(LatArgs a, double *aos) {
   if (p >= a.plane) return;
   const int x = a.x_begin + blockIdx.y;
   const int y = p / a.nz, z = p - y * a.nz;
-  const long node = (long)(x + HALO) * a.plane + p;
+  const long node = (long)(x + HALO) * a.xs + p;
   const Nbr n = neighbours(a, x, y, z);
   double f[HC_Q];
   pull(a.fin, a.qs, node, n, f);
@@ -259,12 +260,13 @@ __global__ void upload_kernel(LatArgs a, const double *aos) {
   if (p >= a.plane) return;
   const int x = a.x_begin + blockIdx.y;
   const int y = p / a.nz, z = p - y * a.nz;
-  const long node = (long)(x + HALO) * a.plane + p;
+  const long node = (long)(x + HALO) * a.xs + p;
   const long bulk = (long)x * a.plane + p;
-  const Nbr n = neighbours(a, x, y, z);
+  Nbr nl = neighbours(a, x, y, z);   // offsets in the unpadded [x][y][z] numbering of the host array
+  nl.xm = nl.xm / a.xs * a.plane; nl.xp = nl.xp / a.xs * a.plane;
 #define M(Q, CX, CY, CZ)                                                                  \
   {                                                                                       \
-    bool ok; long off = dst_off<CX, CY, CZ>(n, ok);                                       \
+    bool ok; long off = dst_off<CX, CY, CZ>(nl, ok);                                      \
     /* without x wrap the +-x neighbour of a face plane is a halo plane: outside */       \
     if (!a.wrap_x && ((CX == 1 && x == a.nx - 1) || (CX == -1 && x == 0))) ok = false;    \
     a.fout[(long)Q * a.qs + node] = ok ? aos[(bulk + off) * HC_Q + Q] : 0.0;            \
@@ -278,7 +280,7 @@ __global__ void rho_u_kernel(LatArgs a, double *rho, double *u) {
   if (p >= a.plane) return;
   const int x = a.x_begin + blockIdx.y;
   const int y = p / a.nz, z = p - y * a.nz;
-  const long node = (long)(x + HALO) * a.plane + p;
+  const long node = (long)(x + HALO) * a.xs + p;
   const Nbr n = neighbours(a, x, y, z);
   double f[HC_Q];
   pull(a.fin, a.qs, node, n, f);
@@ -296,7 +298,7 @@ __global__ void force_aos_kernel(LatArgs a, double *F) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= a.plane) return;
   const int x = a.x_begin + blockIdx.y;
-  const long node = (long)(x + HALO) * a.plane + p;
+  const long node = (long)(x + HALO) * a.xs + p;
   const long o = (long)x * a.plane + p;
   for (int d = 0; d < 3; d++) F[3 * o + d] = a.Fin[d * a.npad + node];
 }
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(256) void fluid_stats_kernel(LatArgs a, int what, d
   const long nbulk = (long)a.nx * a.plane;
   for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nbulk; k += (long)STAT_BLOCKS * 256) {
     const int x = (int)(k / a.plane), p = (int)(k - (long)x * a.plane);
-    const long node = (long)(x + HALO) * a.plane + p;
+    const long node = (long)(x + HALO) * a.xs + p;
     if (what == 2) {   // mass: sum of the stored populations of EVERY bulk node (walls park what bounces back)
       double r = 0.0;
 #pragma unroll
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256) void fluid_stats_kernel(LatArgs a, int what, d
 struct HaloArgs {
   double *f;          // population buffer
   double *buf;        // contiguous staging
-  long npad; int plane;   // npad: population stride
+  long npad; long xs; int plane;   // npad: population stride, xs: x-plane stride
   int n;              // (population, plane) entries
   int pop[HC_Q + 5];  // population of entry e
   int xp[HC_Q + 5];   // padded x index of its plane
@@ -348,18 +350,18 @@ __global__ void halo_copy_kernel(HaloArgs h) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= h.plane) return;
   const int e = blockIdx.y;
-  const long li = (long)h.pop[e] * h.npad + (long)h.xp[e] * h.plane + p;
+  const long li = (long)h.pop[e] * h.npad + (long)h.xp[e] * h.xs + p;
   const long bi = (long)e * h.plane + p;
   if (h.to_buf) h.buf[bi] = h.f[li]; else h.f[li] = h.buf[bi];
 }
 
 // clears the 2*HALO halo planes of the three IBM force components
-__global__ void zero_force_halo_kernel(double *F, long npad, int plane, int nx) {
+__global__ void zero_force_halo_kernel(double *F, long npad, long xs, int plane, int nx) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= plane) return;
   const int comp = blockIdx.y / (2 * HALO), w = blockIdx.y % (2 * HALO);
   const int xp = w < HALO ? w : nx + w;   // padded plane index: 0..HALO-1 and nx+HALO..nx+2*HALO-1
-  F[(long)comp * npad + (long)xp * plane + p] = 0.0;
+  F[(long)comp * npad + (long)xp * xs + p] = 0.0;
 }
 
 LatArgs make_args(const hc_lattice *L) {
@@ -368,7 +370,7 @@ LatArgs make_args(const hc_lattice *L) {
   const int fprev = (L->fcur + 2) % 3;
   a.Fin = L->force[L->fcur]; a.Fzero = L->force[fprev];
   a.mask = L->mask;
-  a.nx = L->nx; a.ny = L->ny; a.nz = L->nz; a.plane = (int)L->plane; a.npad = (long)L->npad; a.qs = (long)L->qstride;
+  a.nx = L->nx; a.ny = L->ny; a.nz = L->nz; a.plane = (int)L->plane; a.xs = (long)L->xs; a.npad = (long)L->npad; a.qs = (long)L->qstride;
   a.x_begin = 0;
   a.wrap_x = (L->n_slabs == 1 && L->periodic[0]) ? 1 : 0;
   a.per_y = L->periodic[1]; a.per_z = L->periodic[2];
@@ -399,7 +401,7 @@ int rebuild_active_map(hc_lattice *L) {
   for (int x = 0; x < NX; x++) {
     int c = 0;
     for (int y = 0; y < ny; y++) {
-      const uint8_t *row = L->hmask.data() + ((size_t)x * ny + y) * nz;
+      const uint8_t *row = L->hmask.data() + (size_t)x * L->xs + (size_t)y * nz;
       int a = 0, b = nz;
       while (a < nz && row[a] == 2) a++;
       while (b > a && row[b - 1] == 2) b--;
@@ -444,14 +446,18 @@ int launch_collide(hc_lattice *L, int x_begin, int nplanes) {
 
 }  // namespace
 
+static int g_force_plane_padding = 0;   // tests / A-B runs: 1 = pad the planes of every lattice, -1 = of none, 0 = by size
+
 extern "C" {
+
+int hc_debug_force_plane_padding(int on) { g_force_plane_padding = on > 0 ? 1 : (on < 0 ? -1 : 0); return HC_OK; }
 
 int hcl_create(hc_lattice **out, int nx, int ny, int nz, const int periodic[3], double omega,
                int x0, int nx_global, int n_slabs) {
   HC_REQUIRE(out && periodic, "hcl_create: null pointer");
   HC_REQUIRE(nx >= 2 && ny >= 2 && nz >= 2, "hcl_create: every dimension must be >= 2");
   HC_REQUIRE(n_slabs >= 1 && nx_global >= nx && x0 >= 0 && x0 + nx <= nx_global, "hcl_create: inconsistent slab decomposition");
-  HC_REQUIRE((long)ny * nz < (1L << 30) && (long)(nx + 2 * HALO) * ny * nz < (1L << 31), "hcl_create: slab too large for 32-bit plane indexing");
+  HC_REQUIRE((long)ny * nz < (1L << 30) && (long)(nx + 2 * HALO) * ((long)ny + 8) * nz < (1L << 31), "hcl_create: slab too large for 32-bit plane indexing");
   HC_REQUIRE(omega > 0.0 && omega < 2.0, "hcl_create: omega must be in (0,2)");
   if (hc::stream() == nullptr) { hc::set_error("hcl_create: hc_init() has not been called"); return HC_ERR_STATE; }
   hc_lattice *L = new hc_lattice();
@@ -460,7 +466,11 @@ int hcl_create(hc_lattice **out, int nx, int ny, int nz, const int periodic[3], 
   L->x0 = x0; L->nx_global = nx_global; L->n_slabs = n_slabs;
   L->omega = omega;
   L->plane = (size_t)ny * nz;
-  L->npad = (size_t)(nx + 2 * HALO) * L->plane;
+  // x-planes whose size is a multiple of 1 MiB (512 x 512 doubles) put the x-1 / x / x+1 planes a kernel streams at the
+  // same time at the same offset in the HBM channel interleave; 8 rows of padding between planes take them apart
+  // (all-fluid 512^3 box: 5.39 -> 5.91 TB/s algorithmic; planes of 512 KiB do not need it, 256^3 runs at 6.0 either way)
+  L->xs = L->plane + ((g_force_plane_padding > 0 || (g_force_plane_padding == 0 && ((L->plane * sizeof(double)) % (1u << 20)) == 0)) ? (size_t)8 * nz : 0);
+  L->npad = (size_t)(nx + 2 * HALO) * L->xs;
   // The 19 population arrays are streamed side by side.  With power-of-two planes (512 x 512 doubles = 2 MiB) and
   // npad a multiple of the plane, all 38 read / write streams of a node sit at the same offset modulo 2 MiB and
   // camp on the same HBM channels (all-fluid 512^3 box: 5.27 TB/s algorithmic against 6.0 for 256^3).  An odd
@@ -487,7 +497,7 @@ int hcl_create(hc_lattice **out, int nx, int ny, int nz, const int periodic[3], 
     HC_HIP(hipMemsetAsync(L->fdirty[k], 0, L->npad / 16 + 1, hc::stream()));
     L->fepoch[k] = 1;
   }
-  L->hmask.assign(L->npad, 0);
+  L->hmask.assign(L->npad, 0);   // device numbering; hcl_set_mask marks the padding
   L->row_z0 = L->row_cum = L->blk_row = nullptr;
   { int rc = rebuild_active_map(L); if (rc != HC_OK) return rc; }
   HC_HIP(hipStreamSynchronize(hc::stream()));
@@ -517,8 +527,13 @@ int hcl_dims(const hc_lattice *L, int dims[3]) {
 
 int hcl_set_mask(hc_lattice *L, const uint8_t *mask_with_halo) {
   HC_REQUIRE(L && mask_with_halo, "hcl_set_mask: null pointer");
-  L->hmask.assign(mask_with_halo, mask_with_halo + L->npad);
-  for (auto &m : L->hmask) m = (m >= 3 && m <= 6) ? m : (m ? 1 : 0);   // 1 = bounce-back, 3..6 = moving-wall classes
+  // host copy in the device numbering (x-planes xs apart); the padding between planes is inert solid
+  L->hmask.assign(L->npad, 2);
+  for (int x = 0; x < L->nx + 2 * HALO; x++)
+    for (size_t p = 0; p < L->plane; p++) {
+      const uint8_t m = mask_with_halo[(size_t)x * L->plane + p];
+      L->hmask[(size_t)x * L->xs + p] = (m >= 3 && m <= 6) ? m : (m ? 1 : 0);   // 1 = bounce-back, 3..6 = moving-wall classes
+    }
   // class 2 = solid node without any fluid neighbour.  Full-way bounce-back returns every population to
   // where it came from, so such a node never exchanges anything with the fluid: the collide kernel skips
   // it (no loads, no stores).  Results on fluid nodes are unchanged, bit for bit.
@@ -529,7 +544,7 @@ int hcl_set_mask(hc_lattice *L, const uint8_t *mask_with_halo) {
     for (int x = 0; x < NX; x++)
       for (int y = 0; y < ny; y++)
         for (int z = 0; z < nz; z++) {
-          const size_t k = ((size_t)x * ny + y) * nz + z;
+          const size_t k = (size_t)x * L->xs + (size_t)y * nz + z;
           if (!L->hmask[k]) continue;
           bool fluid_near = false;
           for (int q = 1; q < HC_Q && !fluid_near; q++) {
@@ -537,7 +552,7 @@ int hcl_set_mask(hc_lattice *L, const uint8_t *mask_with_halo) {
             if (xx < 0 || xx >= NX) { fluid_near = true; break; }   // beyond the halo: unknown, keep the node active
             if (yy < 0 || yy >= ny) { if (L->periodic[1]) yy = (yy + ny) % ny; else continue; }
             if (zz < 0 || zz >= nz) { if (L->periodic[2]) zz = (zz + nz) % nz; else continue; }
-            if (!L->hmask[((size_t)xx * ny + yy) * nz + zz]) fluid_near = true;
+            if (!L->hmask[(size_t)xx * L->xs + (size_t)yy * nz + zz]) fluid_near = true;
           }
           if (!fluid_near) cls[k] = 2;
         }
@@ -599,7 +614,7 @@ int hcl_collide_stream_part(hc_lattice *L, int part) {
     // the kernel zeroes the other-parity IBM force on the bulk planes; envelope copies of cells also
     // spread onto the halo planes, which have to be cleared as well (one small launch)
     hipLaunchKernelGGL(zero_force_halo_kernel, dim3((unsigned)((L->plane + 255) / 256), (unsigned)(2 * HALO * 3), 1), dim3(256), 0, hc::stream(),
-                       L->force[(L->fcur + 2) % 3], (long)L->npad, (int)L->plane, L->nx);
+                       L->force[(L->fcur + 2) % 3], (long)L->npad, (long)L->xs, (int)L->plane, L->nx);
     HC_HIP(hipGetLastError());
   }
   return rc;
@@ -703,7 +718,7 @@ static int halo_copy(hc_lattice *L, int side, int width, double *buf, int to_buf
   static const int cxm[5] = {1, 4, 5, 6, 7};        // c_x = -1
   static const int cxp[5] = {10, 13, 14, 15, 16};   // c_x = +1
   HaloArgs h;
-  h.f = L->f[next ? 1 - L->cur : L->cur]; h.buf = buf; h.npad = (long)L->qstride; h.plane = (int)L->plane; h.to_buf = to_buf; h.n = 0;
+  h.f = L->f[next ? 1 - L->cur : L->cur]; h.buf = buf; h.npad = (long)L->qstride; h.xs = (long)L->xs; h.plane = (int)L->plane; h.to_buf = to_buf; h.n = 0;
   // the populations that travel towards -x (cxm) leave through the low face and arrive in the low neighbour's high
   // halo; those towards +x (cxp) the other way round
   const int *moving = to_buf ? (side == 0 ? cxm : cxp) : (side == 0 ? cxp : cxm);

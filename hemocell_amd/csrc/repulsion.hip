@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void rep_force_kernel(LatView v, long cap, lon
   const int i = vals[s];
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
   if (key != 0xffffffffu) {
-    const int lz = key % v.nz, ly = (key / v.nz) % v.ny, lxp = key / v.plane;   // lxp = padded x
+    const int lxp = (int)(key / v.plane), rem = (int)(key - (long)lxp * v.plane), ly = rem / v.nz, lz = rem - ly * v.nz;   // lxp = padded x
     const double x = px[i], y = py[i], z = pz[i];
     const int ci = vert_cell[i];
     for (int dx = -1; dx <= 1; dx++)
@@ -178,7 +178,7 @@ int hcp_set_boundary_repulsion(hc_cells *C, double br_const, double br_cutoff_lu
     if (L->n_slabs == 1 && !L->periodic[0] && (xp < HALO || xp >= HALO + L->nx)) { known = false; return true; }   // outside the domain
     if (y < 0 || y >= ny) { if (L->periodic[1]) y = (y + ny) % ny; else { known = false; return true; } }
     if (z < 0 || z >= nz) { if (L->periodic[2]) z = (z + nz) % nz; else { known = false; return true; } }
-    return L->hmask[((size_t)xp * ny + y) * nz + z] != 0;
+    return L->hmask[(size_t)xp * L->xs + (size_t)y * nz + z] != 0;
   };
   for (int xp = 0; xp < NX; xp++)
     for (int y = 0; y < ny; y++)
@@ -191,7 +191,7 @@ int hcp_set_boundary_repulsion(hc_cells *C, double br_const, double br_cutoff_lu
           bool k2; const bool s2 = solid(xp + a, y + b, z + c, k2);
           if (k2 && !s2) { near = true; break; }
         }
-        if (near) flag[((size_t)xp * ny + y) * nz + z] = 1;
+        if (near) flag[(size_t)xp * L->xs + (size_t)y * nz + z] = 1;
       }
   if (!C->d_bflag) HC_HIP(hipMalloc((void **)&C->d_bflag, L->npad));
   HC_HIP(hipMemcpy(C->d_bflag, flag.data(), L->npad, hipMemcpyHostToDevice));

@@ -61,6 +61,7 @@ int hc_profile_read(const char *kernel, double *total_ms, long *launches); /* "c
 int hc_profile_reset(void);
 /* A/B switch: 1 = per-vertex IBM kernels with direct global atomics instead of the LDS-tiled per-cell kernels */
 int hc_debug_ibm_per_vertex(int on);
+int hc_debug_force_plane_padding(int on); /* tests / A-B runs: lattices created afterwards get the padded x-plane stride whatever their size (1), never (-1), by size (0, default) */
 
 /* ------------------------------------------------------------------ lattice */
 /* MultiBlockLattice3D<T,DESCRIPTOR>(nx,ny,nz, new GuoExternalForceBGKdynamics(omega))

@@ -24,9 +24,10 @@ FORCE = (3e-4, 0.0, 0.0)
 REPULSION = dict(k=2e-6, cutoff_um=0.7, k_b=3e-6, b_cutoff_um=1.0)   # examples/pipeflow/config.xml:36-38 magnitudes
 
 
-def _build(rank, world, rep=False):
+def _build(rank, world, rep=False, padded=False):
     from hemocell_amd import host
     from hemocell_amd.slab import SlabRunner
+    host.check(host.capi.lib().hc_debug_force_plane_padding(1 if padded else 0))   # padded x-plane stride (hc_lattice::xs)
     P = host.base_parameters()
     r = SlabRunner(NXG // world, NY, NZ, rank, world, P, periodic=(True, False, False), particle_timescale=K_P,
                    material_timescale=K_M, deletion_check_every=1000000)
@@ -49,7 +50,7 @@ def _build(rank, world, rep=False):
     return r, mask
 
 
-def _worker(rank, world, port, out, rep=False):
+def _worker(rank, world, port, out, rep=False, padded=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
@@ -57,7 +58,7 @@ def _worker(rank, world, port, out, rep=False):
     torch.cuda.set_device(0)
     from hemocell_amd import host
     host.init(0)
-    r, _ = _build(rank, world, rep)
+    r, _ = _build(rank, world, rep, padded)
     r.run(STEPS)
     cid, vid, pos = r.owned_vertex_table(0)
     pcid, pvid, ppos = r.owned_vertex_table(1)
@@ -77,12 +78,13 @@ def _initial_x():
     return x
 
 
-@pytest.mark.parametrize("world,rep", [(2, False), (3, False), (2, True)])
-def test_slabs_match_single_domain(tmp_path, gpu, world, rep):
-    """rep: vertex-vertex and boundary-particle repulsion on (cell records then carry force_repulsion)"""
+@pytest.mark.parametrize("world,rep,padded", [(2, False, False), (3, False, False), (2, True, False), (2, True, True)])
+def test_slabs_match_single_domain(tmp_path, gpu, world, rep, padded):
+    """rep: vertex-vertex and boundary-particle repulsion on (cell records then carry force_repulsion);
+    padded: the slabs (not the single-domain reference run) use the padded x-plane stride"""
     import torch.multiprocessing as mp
-    port = 29500 + (os.getpid() + 17 * world + 7 * rep) % 400
-    mp.spawn(_worker, args=(world, port, str(tmp_path), rep), nprocs=world, join=True)
+    port = 29500 + (os.getpid() + 17 * world + 7 * rep + 3 * padded) % 400
+    mp.spawn(_worker, args=(world, port, str(tmp_path), rep, padded), nprocs=world, join=True)
     res = [torch.load(os.path.join(tmp_path, "r%d.pt" % k), weights_only=False) for k in range(world)]
     ref, mask = _build(0, 1, rep)
     ref.run(STEPS)

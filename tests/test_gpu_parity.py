@@ -844,3 +844,29 @@ def test_particle_records_in_the_reference_layout(gpu):
     h.iterate(5)
     assert np.isfinite(cf.positions).all()
     L.destroy()
+
+
+@pytest.mark.parametrize("which", ["collide_111", "collide_000", "pipe", "ibm", "oversized", "iterate_pipe", "iterate_box", "iterate_beside",
+                                   "repulsion", "boundary_repulsion", "info", "records"])
+def test_padded_plane_stride(orc, gpu, which):
+    """lattices whose x-planes are a multiple of 1 MiB (512 x 512 doubles) keep 8 rows of padding between planes
+    (hc_lattice::xs, against HBM channel camping).  The lattices of the parity tests are far smaller, so the padding is
+    forced here and a cross-section of them is run again: every kernel and host routine that turns (x, y, z) into an
+    element index is covered"""
+    lib = gpu.capi.lib()
+    gpu.check(lib.hc_debug_force_plane_padding(1))
+    try:
+        {"collide_111": lambda: test_collide_stream_bit_exact_random_state(orc, gpu, (1, 1, 1)),
+         "collide_000": lambda: test_collide_stream_bit_exact_random_state(orc, gpu, (0, 0, 0)),
+         "pipe": lambda: test_pipe_flow_bit_exact_and_poiseuille(orc, gpu),
+         "ibm": lambda: test_ibm_phases_vs_oracle(orc, gpu),
+         "oversized": lambda: test_ibm_oversized_cells_take_the_fallback_paths(orc, gpu, 1.5, "tile"),
+         "iterate_pipe": lambda: test_iterate_trajectories_vs_oracle(orc, gpu, "pipe_rbc_plt_cadence"),
+         "iterate_box": lambda: test_iterate_trajectories_vs_oracle(orc, gpu, "box_periodic"),
+         "iterate_beside": lambda: test_iterate_trajectories_vs_oracle(orc, gpu, "pipe_rbc_plt_cadence_beside"),
+         "repulsion": lambda: test_repulsion_vs_oracle(orc, gpu),
+         "boundary_repulsion": lambda: test_boundary_particle_repulsion_vs_oracle(orc, gpu),
+         "info": lambda: test_info_reductions_match_downloaded_fields(gpu),
+         "records": lambda: test_particle_records_in_the_reference_layout(gpu)}[which]()
+    finally:
+        gpu.check(lib.hc_debug_force_plane_padding(0))

@@ -24,8 +24,8 @@ import numpy as np  # noqa: E402
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--nx", type=int, default=256, help="slab thickness per GPU")
     ap.add_argument("--ny", type=int, default=256)
     ap.add_argument("--nz", type=int, default=256)

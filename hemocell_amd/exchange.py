@@ -419,9 +419,10 @@ class SlabProtocol:
         collides the interior planes; beside it, on the library's side stream: the arrival of the neighbours' faces, the
         collide of the two face planes, the packing and departure of the 5 crossing populations for the next step, then
         advance, mechanics and (with more=True: another step follows in the same run) the repulsion and spread of the
-        NEXT iteration, none of which depend on the collide.  On a velocity update the wider message an interpolation
-        needs leaves as soon as the two planes next to each face are collided and travels during the interior collide;
-        the id headers of the envelope sync travel and land on the host while the velocities are interpolated."""
+        NEXT iteration, none of which depend on the collide.  On a velocity update the side stream collides the two planes
+        next to each face and sends the wider message an interpolation needs, which travels during the interior collide,
+        then exchanges the id headers of the envelope sync; the records of the crossing cells travel while the velocities
+        of all cells are interpolated."""
         e = self.e
         it = self.iter
         particle_step = it % self.k_p == 0
@@ -444,14 +445,15 @@ class SlabProtocol:
         elif particle_step:
             e.fork()
             with e.side():
-                plans = self.sync_cells_begin()               # which cells cross + id headers: needs positions only, so it
-            self.halo_drain()                                 # travels and lands on the host beside the collide
-            e.collide(4)                                      # the two planes next to each face first ...
-            finish = self.halo_exchange_begin(2, next=True)   # ... so that they travel while the interior is collided
-            e.collide(3)
+                self.halo_drain()
+                e.collide(4)                                  # the two planes next to each face, beside the interior ...
+                finish = self.halo_exchange_begin(2, next=True)   # ... so that the wide message travels during the interior collide
+            e.collide(3)                                      # main stream: interior planes
             e.step_end()
+            with e.side():
+                plans = self.sync_cells_begin()               # which cells cross + id headers: needs positions only; the host
+            e.join()                                          # waits for the extents in there with the interior collide already queued
             finish()
-            e.join()
             states = self.sync_cells_records_begin(plans, True)   # crossing cells interpolated first, their records leave
             e.interpolate()                                   # :327-332, all cells, at halo nodes too
             self.sync_cells_merge(states)

@@ -564,7 +564,7 @@ int hc_iterate(hc_lattice *L, hc_cells *C, long *iter, int n, int particle_times
   // spread(it+1) depend only on vertex data, not on collide(it): they run on the side stream beside it (the spread
   // adds into the force buffer of the next step, which the previous collide left clean).  Never across the end of
   // the call: the caller may edit vertex forces between calls (HemoCellStretch does).
-  struct RouteGuard { ~RouteGuard() { hc::route(0); } } guard;
+  struct ForkGuard { ~ForkGuard() { if (hc::forked()) hc::join(); else hc::route(0); } } guard;   // error paths leave one timeline behind
   const bool may_overlap = g_overlap && !C->rep_enabled && !C->brep_enabled;
   bool spread_done = false;
   int rc;

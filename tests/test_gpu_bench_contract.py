@@ -1,0 +1,43 @@
+"""bench.py prints exactly one JSON line on stdout with the fields the measurement contract names"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]       # nothing but the result on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_small_pipe(gpu):
+    j = _run(["--nx", "64", "--ny", "66", "--nz", "66", "--steps", "20", "--warmup", "5", "--cpu-seconds", "2"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["unit"] == "MLUPS" and j["n_gpus"] == 1 and j["steps"] == 20 and j["warmup"] == 5 and j["dtype"] == "f64"
+    assert j["higher_is_better"] is True and j["vs_baseline"] is None and j["scaling"] == "weak" and j["data"] == "synthetic"
+    assert abs(j["value"] - 64 * 66 * 66 / (j["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * j["value"]
+    assert "workload" in j["config"] and "model" not in j["config"]
+    rf = j["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rf, key
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches"] == 20
+    assert rf["traffic"] is None                   # the PMC figure belongs to the 256^3 headline workload only
+    cb = j["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cb, key
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    # every iteration is in exactly one of the two collide classes, and the schedule of section 4a of DESIGN.md was used
+    k = j["kernel_ms"]
+    assert k["collide_stream_alone"]["launches"] + k["collide_stream_beside"]["launches"] == 20
+    assert k["collide_stream_beside"]["launches"] > 0 and k["ibm_interpolate"]["launches"] == 4

@@ -1,0 +1,64 @@
+"""python examples/pipe/run_headline.py [workdir]
+
+The headline workload of bench.py (pipe 256^3, 10 % hematocrit, stepParticleEvery 5, stepMaterialEvery 20) driven the way a
+HemoCell user drives it: the reference-style case driver pipe_synthetic.cpp, compiled against the C++ facade
+(hemocell_amd/compat) and linked with libhemocell_amd.so, reading config.xml / RBC.xml / RBC.pos.  It calls
+hemocell.iterate() once per iteration and re-applies the driving force after it, as examples/pipeflow/pipeflow.cpp does.
+The time per iteration is taken from two runs that differ only in tmax."""
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from hemocell_amd.packing import pack_pipe_rbc   # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+N = 256
+CONFIG = """<?xml version="1.0" ?>
+<hemocell>
+<parameters> <warmup> 0 </warmup> <outputDirectory>tmp_out</outputDirectory> </parameters>
+<ibm> <stepMaterialEvery> 20 </stepMaterialEvery> <stepParticleEvery> 5 </stepParticleEvery> </ibm>
+<domain> <rhoP> 1025 </rhoP> <nuP> 1.1e-6 </nuP> <dx> 5e-7 </dx> <dt> 1e-7 </dt>
+    <refDirN> %d </refDirN> <lengthN> %d </lengthN> <kBT> 4.100531391e-21 </kBT> <Re> 0.5 </Re> </domain>
+<sim> <tmax> %d </tmax> <tmeas> %d </tmeas> <tcheckpoint> 100000000 </tcheckpoint> </sim>
+</hemocell>
+"""
+
+
+def main():
+    work = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "tmp_headline")
+    os.makedirs(work, exist_ok=True)
+    libdir = os.path.join(ROOT, "hemocell_amd", "lib")
+    drv = os.path.join(work, "pipe_synthetic")
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wno-deprecated-declarations", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "hemocell_amd", "compat"), os.path.join(HERE, "pipe_synthetic.cpp"), "-o", drv,
+                           "-L" + libdir, "-lhemocell_amd", "-Wl,-rpath," + libdir])
+    centres, angles = pack_pipe_rbc(N, N, N, 0.10)
+    with open(os.path.join(work, "RBC.pos"), "w") as f:       # micrometres and degrees, io/readPositionsBloodCells.cpp:218-227
+        f.write("%d\n" % len(centres))
+        for c, a in zip(centres, angles):
+            f.write("%.6f %.6f %.6f %.4f %.4f %.4f\n" % (c[0] * 0.5, c[1] * 0.5, c[2] * 0.5, a[0], a[1], a[2]))
+    with open(os.path.join(work, "PLT.pos"), "w") as f:
+        f.write("0\n")
+    for name in ("RBC.xml", "PLT.xml"):
+        shutil.copy(os.path.join(HERE, name), os.path.join(work, name))
+    times, stats = {}, {}
+    for tmax in (100, 500):
+        with open(os.path.join(work, "config.xml"), "w") as f:
+            f.write(CONFIG % (N - 2, N, tmax, tmax))
+        shutil.rmtree(os.path.join(work, "tmp_out"), ignore_errors=True)
+        t0 = time.perf_counter()
+        out = subprocess.run([drv, "config.xml"], cwd=work, capture_output=True, text=True, check=True).stdout
+        times[tmax] = time.perf_counter() - t0
+        stats[tmax] = [l for l in out.splitlines() if l.startswith("STAT")][-1]
+    ms = (times[500] - times[100]) / 400 * 1e3
+    cells = int(stats[500].split()[2])
+    print("reference-style driver through the facade, pipe %d^3, %d cells: %.4f ms per iterate() = %.0f MLUPS   [%s]"
+          % (N, cells, ms, N ** 3 / ms / 1e3, stats[500]))
+
+
+if __name__ == "__main__":
+    main()

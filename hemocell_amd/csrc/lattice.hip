@@ -457,7 +457,7 @@ int hcl_create(hc_lattice **out, int nx, int ny, int nz, const int periodic[3], 
   HC_REQUIRE(out && periodic, "hcl_create: null pointer");
   HC_REQUIRE(nx >= 2 && ny >= 2 && nz >= 2, "hcl_create: every dimension must be >= 2");
   HC_REQUIRE(n_slabs >= 1 && nx_global >= nx && x0 >= 0 && x0 + nx <= nx_global, "hcl_create: inconsistent slab decomposition");
-  HC_REQUIRE((long)ny * nz < (1L << 30) && (long)(nx + 2 * HALO) * ((long)ny + 8) * nz < (1L << 31), "hcl_create: slab too large for 32-bit plane indexing");
+  HC_REQUIRE((long)ny * nz < (1L << 30) && (long)(nx + 2 * HALO) * (((long)ny + 8) * nz + 32) < (1L << 31), "hcl_create: slab too large for 32-bit plane indexing");
   HC_REQUIRE(omega > 0.0 && omega < 2.0, "hcl_create: omega must be in (0,2)");
   if (hc::stream() == nullptr) { hc::set_error("hcl_create: hc_init() has not been called"); return HC_ERR_STATE; }
   hc_lattice *L = new hc_lattice();
@@ -466,10 +466,14 @@ int hcl_create(hc_lattice **out, int nx, int ny, int nz, const int periodic[3], 
   L->x0 = x0; L->nx_global = nx_global; L->n_slabs = n_slabs;
   L->omega = omega;
   L->plane = (size_t)ny * nz;
-  // x-planes whose size is a multiple of 1 MiB (512 x 512 doubles) put the x-1 / x / x+1 planes a kernel streams at the
-  // same time at the same offset in the HBM channel interleave; 8 rows of padding between planes take them apart
-  // (all-fluid 512^3 box: 5.39 -> 5.91 TB/s algorithmic; planes of 512 KiB do not need it, 256^3 runs at 6.0 either way)
-  L->xs = L->plane + ((g_force_plane_padding > 0 || (g_force_plane_padding == 0 && ((L->plane * sizeof(double)) % (1u << 20)) == 0)) ? (size_t)8 * nz : 0);
+  // x-plane stride.  (1) A multiple of 16 doubles, so that the x-1 / x+1 neighbours of a 128-byte line are lines too: with
+  // an odd plane (the reference's voxelised tubes are 2N+3 x N+3 x N+3 nodes) every read of a population that moves along
+  // x straddles one line more (511 x 257 x 257 pipe: -8 % against 512 x 256 x 257).  (2) x-planes whose size is a multiple
+  // of 1 MiB (512 x 512 doubles) put the x-1 / x / x+1 planes a kernel streams at the same time at the same offset in the
+  // HBM channel interleave; 8 rows of padding between planes take them apart (all-fluid 512^3 box: about +5 %).
+  L->xs = (L->plane + 15) / 16 * 16;
+  if (g_force_plane_padding > 0 || (g_force_plane_padding == 0 && ((L->plane * sizeof(double)) % (1u << 20)) == 0)) L->xs += (size_t)(8 * nz + 15) / 16 * 16;
+  if (g_force_plane_padding < 0) L->xs = L->plane;
   L->npad = (size_t)(nx + 2 * HALO) * L->xs;
   // The 19 population arrays are streamed side by side.  With power-of-two planes (512 x 512 doubles = 2 MiB) and
   // npad a multiple of the plane, all 38 read / write streams of a node sit at the same offset modulo 2 MiB and

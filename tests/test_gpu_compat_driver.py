@@ -246,3 +246,33 @@ def test_reference_onecellshear_driver_runs_config_c1(tmp_path, gpu):
     centre = [l for l in r.stdout.splitlines() if "Cell center at" in l][-1]
     z = float(centre.split("{")[1].split("}")[0].split(",")[2])
     assert 3.0 < z < 7.0                                                                # stays between the walls (box height 10 um)
+
+
+def test_reference_performance_testing_driver_runs_its_1_rank_case(tmp_path, gpu):
+    """cases/performance_testing/performance_testing.cpp (compiled unchanged) on the reference's own inputs for the 1-rank
+    case of its strong-scaling series (tests/golden/performance_case: 256^3 fully periodic, hematocrit_33/RBC.pos,
+    velocities interpolated every step).  The reference holds no known answer for this case: the checks are that every
+    cell of the .pos file that lies in the 128 um domain is placed and none is lost, and that the flow responds to the
+    body force (statistics printed by the driver itself)."""
+    drv = os.path.join(ROOT, "build", "ref_drivers", "performance_testing_nohdf5")
+    if not os.path.exists(drv):
+        pytest.skip("build/ref_drivers/performance_testing_nohdf5 is built by __graft_entry__.build() where the reference tree is present")
+    import re
+    import shutil
+    case = os.path.join(ROOT, "tests", "golden", "performance_case")
+    for name in ("RBC.xml", "RBC.pos"):
+        shutil.copy(os.path.join(case, name), str(tmp_path / name))
+    cfg = open(os.path.join(case, "config.xml")).read()
+    cfg = re.sub(r"<tmax>[^<]*</tmax>", "<tmax> 100 </tmax>", cfg)
+    cfg = re.sub(r"<tmeas>[^<]*</tmeas>", "<tmeas> 50 </tmeas>", cfg)
+    (tmp_path / "config.xml").write_text(cfg)
+    r = subprocess.run([drv, "config.xml"], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    pos = np.loadtxt(os.path.join(case, "RBC.pos"), skiprows=1)[:, :3] * 2.0          # lattice units (dx = 0.5 um)
+    expected = int(((pos > -0.5) & (pos <= 255.5)).all(axis=1).sum())                # nearest node inside the 256^3 domain
+    assert int(re.search(r"nCells \(global\) = (\d+)", r.stdout).group(1)) == expected == 9358
+    counts = [int(m) for m in re.findall(r"# of cells: (\d+)", r.stdout)]
+    assert counts == [expected, expected], counts
+    means = [float(m) for m in re.findall(r"mean: ([0-9.eE+-]+) m/s", r.stdout)]
+    assert len(means) == 2 and 0 < means[0] < means[1] < 1e-3, means                  # accelerating from rest, far below lattice speed
+    assert "Simulation finished" in r.stdout

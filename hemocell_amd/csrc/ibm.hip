@@ -337,8 +337,17 @@ __global__ __launch_bounds__(256) void ibm_interpolate_cell_kernel(LatView v, Po
 #pragma unroll
       for (int k = 0; k < 8; k++) if (vs[j].adm & (1u << k)) slot[vs[j].base + (k >> 2) * sx + ((k >> 1) & 1) * sy + (k & 1)] = MARK;
     __syncthreads();
-    for (int i = tid; i < t.vol; i += nth) {   // compact
-      if (slot[i] == MARK) { const int n = atomicAdd(&s_count, 1); if (n < NODE_CAP) { slot[i] = (unsigned short)n; list[n] = (unsigned short)i; } }
+    for (int i0 = 0; i0 < t.vol; i0 += nth) {   // compact: one LDS atomic per wave, ranks within the wave from its ballot
+      const int i = i0 + tid;
+      const bool marked = i < t.vol && slot[i] == MARK;
+      const unsigned long long b = __ballot(marked);
+      int first = 0;
+      if ((tid & 63) == 0 && b) first = atomicAdd(&s_count, (int)__popcll(b));
+      first = __shfl(first, 0);
+      if (marked) {
+        const int n = first + (int)__popcll(b & ((1ull << (tid & 63)) - 1ull));
+        if (n < NODE_CAP) { slot[i] = (unsigned short)n; list[n] = (unsigned short)i; }
+      }
     }
     __syncthreads();
     if (s_count > NODE_CAP) tiled = false;   // uniform: s_count is shared

@@ -230,10 +230,10 @@ def main():
         # passes, FETCH doubled per the gfx950 note): measured offline on exactly this workload and committed under
         # profiles/; reported only when the run matches the workload of that measurement
         traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "r01_i_traffic.json")
+        tf = os.path.join(ROOT, "profiles", "r01_j_traffic.json")
         if os.path.exists(tf) and (args.nx, args.ny, args.nz) == (256, 256, 256) and not args.fluid_only and abs(args.hematocrit - 0.10) < 1e-12:
             tj = json.load(open(tf))
-            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01_i_traffic.json (rocprofv3 --pmc, %.1f B/node)" % tj["hbm_bytes_per_node"]
+            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01_j_traffic.json (rocprofv3 --pmc, %.1f B/node)" % tj["hbm_bytes_per_node"]
         out = {
             "metric": "MLUPS + cell-vertex updates/s, 256^3 pipeflow 10% Hct",
             "value": mlups, "unit": "MLUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -41,3 +41,22 @@ def test_bench_line_small_pipe(gpu):
     k = j["kernel_ms"]
     assert k["collide_stream_alone"]["launches"] + k["collide_stream_beside"]["launches"] == 20
     assert k["collide_stream_beside"]["launches"] > 0 and k["ibm_interpolate"]["launches"] == 4
+
+
+def test_bench_two_ranks_share_the_gpu_over_gloo(gpu):
+    """the N > 1 path of bench.py as the driver launches it (torch.distributed.run, one rank per GPU), rehearsed with two
+    ranks on the one GPU of the test box; RCCL refuses two ranks on one device, so the transport is gloo here
+    (HEMOCELL_DIST_BACKEND), everything else -- slab protocol, streams, timing, reduction of the result -- is the same code"""
+    env = dict(os.environ, HEMOCELL_DIST_BACKEND="gloo")
+    port = str(29700 + os.getpid() % 200)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nx", "64", "--ny", "66", "--nz", "66",
+           "--steps", "20", "--warmup", "5"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["lattice"] == [128, 66, 66]
+    assert j["value"] > 0 and j["config"]["cells"] > 0 and "cpu_baseline" not in j      # the CPU baseline is an N = 1 item
+    assert abs(j["value"] - 128 * 66 * 66 / (j["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * j["value"]

@@ -216,6 +216,18 @@ def main():
         host.capi.check(host.capi.lib().hc_profile_read(k.encode(), C.byref(m2), C.byref(n2)))
         prof[k] = {"ms_total": m2.value, "launches": n2.value}
 
+    def copy_bandwidth():
+        """device-to-device copy of 1 GiB on this very GPU, read + written bytes per second: what the box in hand delivers
+        (the boxes of the pool differ by several per cent); the roofline peak stays the 8 TB/s of the specification"""
+        a = torch.empty(1 << 27, dtype=torch.float64, device="cuda"); b = torch.empty_like(a)
+        a.fill_(1.0); b.copy_(a); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b.copy_(a)
+        e1.record(); torch.cuda.synchronize()
+        return 10 * 2 * a.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
     if rank == 0:
         nodes = nxg * args.ny * args.nz
         mlups = nodes * args.steps / elapsed / 1e6
@@ -250,7 +262,8 @@ def main():
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": launch_nodes * bytes_per_node,
                          "bytes_per_node": bytes_per_node, "nodes_per_launch": launch_nodes, "avg_launch_ms": avg_ms,
-                         "launches": n.value, "peak_source": "MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)"},
+                         "launches": n.value, "peak_source": "MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)",
+                         "torch_copy_GBps_this_gpu": copy_bandwidth()},
             "kernel_ms": prof,
             # the same kernel over the launches that had the GPU to themselves (velocity-update steps); the others share
             # it with advance + spread of the next iteration on the side stream, which stretches both

@@ -32,7 +32,7 @@ def test_bench_line_small_pipe(gpu):
         assert key in rf, key
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches"] == 20
-    assert rf["traffic"] is None                   # the PMC figure belongs to the 256^3 headline workload only
+    assert rf["torch_copy_GBps_this_gpu"] > 1000 and rf["traffic"] is None                   # the PMC figure belongs to the 256^3 headline workload only
     cb = j["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key

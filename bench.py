@@ -6,12 +6,18 @@ A "step" is one HemoCell::iterate(): spread -> collide-stream -> [interpolate] -
 with the reference's pipeflow cadences (stepParticleEvery 5, stepMaterialEvery 20,
 examples/pipeflow/config.xml:19-20).  Inputs are resident in HBM before the timed region.
 
-N GPUs (weak scaling): the pipe is N x (256x256x256) long; each rank owns one 256-plane x-slab with its
-own cells, x-halos are exchanged every step over RCCL (torch.distributed, backend nccl).
+N GPUs (weak scaling): the pipe is N x (256x256x256) long; each rank owns one 256-plane x-slab with its own cells.  The
+ranks are one process per GPU; the slab schedule runs inside libhemocell_amd.so (csrc/slab.hip): the faces cross every
+step, the particle envelopes at every velocity update, over RCCL point-to-point (ncclSend / ncclRecv between x-neighbours
+on the library's side stream) beside the interior collide.  Launch: `python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are read from the environment), or plain
+`python bench.py --gpus N`, which starts the N ranks itself.
 """
 import argparse
+import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -40,6 +46,9 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true",
                     help="A/B: one stream only (by default advance, mechanics and the next spread run beside the collide between velocity updates)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--transport", choices=["rccl", "tcp"], default=None,
+                    help="data plane of an N > 1 run: rccl (default), or tcp = the same messages through the library's host mesh, "
+                         "for ranks that share a GPU (rehearsal on a one-GPU box); also HEMOCELL_TRANSPORT")
     return ap.parse_args()
 
 
@@ -94,6 +103,8 @@ def cpu_baseline(args, budget_s):
     dt = time.perf_counter() - t0
     nverts = S.contents.np
     return {"value": nx * ny * nz * steps / dt / 1e6, "unit": "MLUPS", "cores": cores, "kind": "port",
+            "mlups_per_core": nx * ny * nz * steps / dt / 1e6 / cores,
+            "sample_nodes_over_gpu_nodes": nx * ny * nz / float(args.nx * args.ny * args.nz),
             "sample": "oracle (oracle/hemo_oracle.c, OpenMP collide-stream, IBM and mechanics), pipe %dx%dx%d, %d RBC "
                       "(%d vertices), %d steps in %.1f s" % (nx, ny, nz, ncell, nverts, steps, dt),
             "vertex_updates_per_s": nverts * steps / dt}
@@ -106,52 +117,57 @@ def body_force(ny, nu_lbm, Re=0.5):
     return (8.0 * nu_lbm * (u_max * 0.5) / (R * R), 0.0, 0.0)
 
 
+def launch_ranks(args):
+    """plain `python bench.py --gpus N`: start the N ranks as child processes (one per GPU, nothing in this process has
+    touched the GPU), hand rank 0's stdout through, fail if any rank fails"""
+    port = 29400 + os.getpid() % 2000
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        sys.exit("bench.py: ranks exited with %s" % rcs)
+
+
 def main():
     args = parse()
-    # stdout carries exactly one line, the JSON result: RCCL prints its version banner to stdout (and gloo its
-    # connection notes), so everything else that writes to file descriptor 1 is sent to stderr
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1:
+        return launch_ranks(args)
+    if world != args.gpus:
+        sys.exit("bench.py --gpus %d was started in a world of %d ranks" % (args.gpus, world))
+    # stdout carries exactly one line, the JSON result: RCCL prints its version banner to stdout, so everything else
+    # that writes to file descriptor 1 is sent to stderr
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-    import torch
-    import torch.distributed as dist
+    if args.transport:
+        os.environ["HEMOCELL_TRANSPORT"] = args.transport
 
-    from hemocell_amd import host
+    from hemocell_amd import host, slab
     from hemocell_amd.packing import pack_pipe_rbc
     from hemocell_amd.slab import SlabRunner
 
-    if os.environ.get("HEMOCELL_DIST_BACKEND", "nccl") != "nccl":
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
+    lib = host.capi.lib()
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL ("nccl") is the transport; HEMOCELL_DIST_BACKEND=gloo only exists so that the N>1 code path can
-        # be rehearsed with several ranks sharing one GPU
-        backend = os.environ.get("HEMOCELL_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    host.init(local_rank)
+        rank, world = slab.comm_init_env()     # connects the ranks and selects GPU LOCAL_RANK (modulo the device count)
+    else:
+        rank = 0
+        host.init(0)
     if args.no_overlap:
-        host.capi.check(host.capi.lib().hc_set_overlap(0))
-    host.capi.check(host.capi.lib().hc_debug_force_plane_padding({"auto": 0, "on": 1, "off": -1}[args.plane_padding]))
+        host.check(lib.hc_set_overlap(0))
+    host.check(lib.hc_debug_force_plane_padding({"auto": 0, "on": 1, "off": -1}[args.plane_padding]))
 
     # examples/pipeflow/config.xml:25-28: dx 5e-7, dt 1e-7, nuP 1.1e-6 -> tau 1.82; performance_testing: dt = -1 -> tau = 1
     P = host.base_parameters(dt=-1.0) if args.periodic_box else host.base_parameters()
     nxg = args.nx * world
+    # every-step deletion semantics (core/hemoCellParticleField.cpp:566-588): the check lives in the advance kernel
     runner = SlabRunner(nx_local=args.nx, ny=args.ny, nz=args.nz, rank=rank, world=world, P=P,
                         periodic=(True, True, True) if args.periodic_box else (True, False, False),
                         particle_timescale=5, material_timescale=20,
-                        deletion_check_every=1000000, fluid_only=args.fluid_only or args.periodic_box)
-    if args.no_overlap and runner.exchange is not None:
-        runner.exchange.protocol.overlap = False
+                        deletion_check_every=1, fluid_only=args.fluid_only or args.periodic_box)
     mask, R = host.pipe_mask(nxg, args.ny, args.nz)
     if args.periodic_box:
         mask[:] = 0
@@ -165,105 +181,108 @@ def main():
         rbc = host.CellType.rbc(P)
         runner.add_cell_type(rbc)
         centres, angles = pack_pipe_rbc(nxg, args.ny, args.nz, args.hematocrit)
-        n_cells = runner.load_cells(0, centres, angles)
+        runner.load_cells(0, centres, angles)
         if args.plt_ratio > 0:
             # platelets (66 vertices, 2.5 x 1.1 um discs) in the gaps of the RBC grid: half a pitch off in x and z
             plt_t = runner.add_cell_type(host.CellType.plt(P))
             pick = np.arange(0, len(centres), max(1, int(round(1.0 / args.plt_ratio))))
             pc = centres[pick] + np.array([9.5, 0.0, 0.0]); pc[:, 2] += np.where(pc[:, 2] > args.nz / 2, -4.6, 4.6)
             pa = np.tile(np.array([90.0, 0.0, 0.0]), (len(pc), 1))
-            n_plt = runner.load_cells(plt_t, pc, pa)
-            n_cells += n_plt
+            runner.load_cells(plt_t, pc, pa)
+        n_cells = int(runner.sync_placement().sum())     # distinct cells over all slabs
     runner.prepare()
     nverts_local = runner.owned_vertices()
 
     def barrier():
+        host.check(lib.hc_synchronize())
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        host.capi.check(host.capi.lib().hc_synchronize())
+            slab.barrier()
 
     runner.run(args.warmup)
-    import gc
-    gc.collect()   # nothing of the set-up is left for a collection inside the timed region (slab runs are driven from
-    gc.freeze()    # Python: a full collection with torch loaded takes ~65 ms, during which no step is enqueued)
-    gc.disable()
-    host.capi.lib().hc_profile_reset()
-    host.capi.lib().hc_profile_enable(0 if args.no_kernel_profile else 1)
+    runner.slab_stats(reset=True)
+    lib.hc_profile_reset()
+    lib.hc_profile_enable(0 if args.no_kernel_profile else 1)
     barrier()
     t0 = time.perf_counter()
     runner.run(args.steps)
     barrier()
     t1 = time.perf_counter()
-    gc.enable()
-    host.capi.lib().hc_profile_enable(0)
+    lib.hc_profile_enable(0)
     elapsed = t1 - t0
+    sstats = runner.slab_stats()
+    counts = np.zeros(3, dtype=np.int64)
+    host.check(lib.hcl_node_counts(runner.lattice.ptr, host.lptr(counts)))
     if world > 1:
-        tt = torch.tensor([elapsed, float(nverts_local)], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0]); nverts = int(tsum[1])
-        n_cells = nverts // 642 if args.plt_ratio == 0 else n_cells
+        elapsed = float(slab.allreduce([elapsed], "max")[0])            # the slowest rank sets the time of the job
+        tot = slab.allreduce([float(nverts_local), float(counts[1]), float(counts[2]), sstats["host_s"], sstats["header_wait_s"]], "sum")
+        nverts = int(tot[0]); fluid_nodes, active_nodes = int(tot[1]), int(tot[2])
+        host_ms_per_step = tot[3] / world / args.steps * 1e3
+        header_wait_ms = tot[4] / world / max(sstats["particle_steps"], 1) * 1e3
     else:
-        nverts = nverts_local
+        nverts = nverts_local; fluid_nodes, active_nodes = int(counts[1]), int(counts[2])
+        host_ms_per_step = header_wait_ms = None
 
-    import ctypes as C
     ms, n = C.c_double(), C.c_long()
-    host.capi.check(host.capi.lib().hc_profile_read(b"collide_stream", C.byref(ms), C.byref(n)))
+    host.check(lib.hc_profile_read(b"collide_stream", C.byref(ms), C.byref(n)))
     prof = {}
     for k in ("collide_stream", "collide_stream_alone", "collide_stream_beside", "ibm_spread", "ibm_interpolate", "advance", "mechanics"):
         m2, n2 = C.c_double(), C.c_long()
-        host.capi.check(host.capi.lib().hc_profile_read(k.encode(), C.byref(m2), C.byref(n2)))
+        host.check(lib.hc_profile_read(k.encode(), C.byref(m2), C.byref(n2)))
         prof[k] = {"ms_total": m2.value, "launches": n2.value}
-
-    def copy_bandwidth():
-        """device-to-device copy of 1 GiB on this very GPU, read + written bytes per second: what the box in hand delivers
-        (the boxes of the pool differ by several per cent); the roofline peak stays the 8 TB/s of the specification"""
-        a = torch.empty(1 << 27, dtype=torch.float64, device="cuda"); b = torch.empty_like(a)
-        a.fill_(1.0); b.copy_(a); torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            b.copy_(a)
-        e1.record(); torch.cuda.synchronize()
-        return 10 * 2 * a.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
     if rank == 0:
         nodes = nxg * args.ny * args.nz
         mlups = nodes * args.steps / elapsed / 1e6
         bytes_per_node = runner.lattice.bytes_per_node()   # 19+19 populations, 3+3 force doubles, 1 mask byte
         # dominant kernel: collide_stream_kernel.  Per step and rank it processes the nx*ny*nz nodes of the slab
-        # (one launch, or an interior + two boundary-plane launches when halos are in flight); the hipEvent
-        # brackets are on the stream the kernel runs on (hc_profile_*), rank 0's numbers are reported.
+        # (one launch, or an interior + boundary-plane launches when faces are in flight); the hipEvent brackets are on the
+        # stream the kernel runs on (hc_profile_*), rank 0's numbers are reported.
         launch_nodes = args.nx * args.ny * args.nz
         avg_ms = ms.value / args.steps
         achieved = launch_nodes * bytes_per_node / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM bytes per launch of that kernel from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-        # passes, FETCH doubled per the gfx950 note): measured offline on exactly this workload and committed under
-        # profiles/; reported only when the run matches the workload of that measurement
-        traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "r01_j_traffic.json")
-        if os.path.exists(tf) and (args.nx, args.ny, args.nz) == (256, 256, 256) and not args.fluid_only and abs(args.hematocrit - 0.10) < 1e-12:
-            tj = json.load(open(tf))
-            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01_j_traffic.json (rocprofv3 --pmc, %.1f B/node)" % tj["hbm_bytes_per_node"]
+        # passes, FETCH doubled per the gfx950 note): measured offline on exactly this workload AND this build of the kernel
+        # (hc_build_tag = hash of csrc/lattice.hip) and committed under profiles/; otherwise null
+        traffic, traffic_src, traffic_per_node = None, None, None
+        tag = lib.hc_build_tag().decode()
+        if (args.nx, args.ny, args.nz) == (256, 256, 256) and not args.fluid_only and abs(args.hematocrit - 0.10) < 1e-12 and args.plt_ratio == 0:
+            for tf in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")), reverse=True):
+                tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
+                if tj.get("kernel_tag") == tag:
+                    traffic, traffic_per_node = tj["hbm_bytes_per_launch"], tj["hbm_bytes_per_node"]
+                    traffic_src = "profiles/%s (rocprofv3 --pmc, %.1f B/node, kernel build %s)" % (tf, traffic_per_node, tag)
+                    break
+        cbw = C.c_double()
+        host.check(lib.hc_measure_copy_bandwidth(1 << 30, 10, C.byref(cbw)))
         out = {
             "metric": "MLUPS + cell-vertex updates/s, 256^3 pipeflow 10% Hct",
             "value": mlups, "unit": "MLUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "vertex_updates_per_s": nverts * args.steps / elapsed,
+            # the same rate counted over the fluid nodes only, and what share of the box the kernel touches
+            "mlups_fluid_nodes": fluid_nodes * args.steps / elapsed / 1e6,
+            "fluid_node_fraction": fluid_nodes / nodes, "active_node_fraction": active_nodes / nodes,
             "config": {"workload": "examples/pipeflow synthetic: pipe %dx%dx%d (x periodic, analytic cylinder R=%.0f, bounce-back), "
                                    "%d cells (rbcHighOrderModel, 642 vertices each, target Hct %.2f; pltSimpleModel platelets per RBC: %g), tau=%.2f, "
-                                   "stepParticleEvery=5, stepMaterialEvery=20%s"
+                                   "stepParticleEvery=5, stepMaterialEvery=20, wall deletions checked every step%s"
                                    % (nxg, args.ny, args.nz, R, n_cells, args.hematocrit, args.plt_ratio, P.tau, (", fully periodic box without walls (cases/performance_testing)" if args.periodic_box else ", fluid only") if args.fluid_only else ""),
                        "lattice": [nxg, args.ny, args.nz], "cells": n_cells, "vertices": nverts,
-                       "parallelism": "x-slabs x%d, RCCL halo exchange" % world},
+                       "parallelism": "x-slabs x%d, native slab schedule (csrc/slab.hip), %s point-to-point" % (world, {0: "no", 1: "RCCL", 2: "TCP-staged"}[slab.comm_info()[2]]) if world > 1 else "1 GPU"},
+            # `achieved` / `frac` follow SURVEY.md section 8(d): ALGORITHMIC bytes (353 B x every node of the box, solid ones
+            # included) over the kernel's time.  The kernel skips inert solid nodes, so the bytes that really move are fewer:
+            # `traffic` (PMC) and `frac_real_traffic` = traffic / time / peak say what the HBM actually delivered.
             "roofline": {"bound": "hbm", "kernel": "collide_stream_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac_real_traffic": (traffic / (avg_ms * 1e-3) / 8.0e12) if (traffic and avg_ms > 0) else None,
+                         "real_traffic_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
+                         # without a PMC figure for this workload: the bytes of the nodes the kernel visits (an upper bound of what moves)
+                         "frac_active_nodes": (active_nodes / world) * bytes_per_node / (avg_ms * 1e-3) / 8.0e12 if avg_ms > 0 else None,
                          "algorithmic_bytes_per_launch": launch_nodes * bytes_per_node,
                          "bytes_per_node": bytes_per_node, "nodes_per_launch": launch_nodes, "avg_launch_ms": avg_ms,
-                         "launches": n.value, "peak_source": "MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)",
-                         "torch_copy_GBps_this_gpu": copy_bandwidth()},
+                         "launches": n.value, "kernel_build": tag,
+                         "peak_source": "MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)",
+                         "copy_GBps_this_gpu": cbw.value},
             "kernel_ms": prof,
             # the same kernel over the launches that had the GPU to themselves (velocity-update steps); the others share
             # it with advance + spread of the next iteration on the side stream, which stretches both
@@ -275,11 +294,16 @@ def main():
             # aggregate 8 TB/s of the GPUs used (north_star: >= 0.60 on the 512^3 pipe at 1 GPU)
             "whole_step_hbm_frac": mlups * 1e6 * bytes_per_node / (8.0e12 * world),
         }
+        if world > 1:
+            out["slab_schedule"] = {"host_ms_per_step": host_ms_per_step, "header_wait_ms_per_velocity_update": header_wait_ms,
+                                    "records_sent_rank0": sstats["cells_sent"], "copies_created_rank0": sstats["cells_new"],
+                                    "copies_dropped_rank0": sstats["cells_dropped"]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
-        dist.destroy_process_group()
+        slab.barrier()
+        slab.comm_finalize()
 
 
 if __name__ == "__main__":

@@ -44,9 +44,28 @@ SIGNATURES = {
     "hc_join": (C.c_int, []),
     "hc_side_stream": (C.c_int, [C.POINTER(VP)]),
     "hc_set_overlap": (C.c_int, [C.c_int]),
+    "hc_comm_init_env": (C.c_int, []),
+    "hc_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int]),
+    "hc_comm_finalize": (C.c_int, []),
+    "hc_comm_info": (C.c_int, [c_int_p, c_int_p, c_int_p]),
+    "hc_comm_barrier": (C.c_int, []),
+    "hc_comm_allreduce": (C.c_int, [c_double_p, C.c_int, C.c_int]),
+    "hc_comm_bcast": (C.c_int, [VP, C.c_size_t, C.c_int]),
+    "hc_comm_allgather": (C.c_int, [VP, C.c_size_t, VP]),
+    "hc_comm_exchange_host": (C.c_int, [C.c_int, VP, C.c_size_t, VP, C.c_size_t, VP, C.c_size_t, VP, C.c_size_t]),
+    "hc_slab_stats": (C.c_int, [VP, c_double_p, C.c_int]),
+    "hcl_slab_refresh_halos": (C.c_int, [VP, C.c_int]),
+    "hcp_slab_sync_placement": (C.c_int, [VP, c_long_p]),
+    "hcp_set_deletion_mode": (C.c_int, [VP, C.c_int]),
+    "hcp_delete_incomplete_cells": (C.c_int, [VP, c_long_p]),
+    "hcp_deletion_counts": (C.c_int, [VP, c_long_p, c_long_p, c_long_p, c_long_p]),
+    "hcp_download_alive": (C.c_int, [VP, VP]),
     "hc_profile_enable": (C.c_int, [C.c_int]),
     "hc_profile_read": (C.c_int, [C.c_char_p, c_double_p, c_long_p]),
     "hc_profile_reset": (C.c_int, []),
+    "hc_build_tag": (C.c_char_p, []),
+    "hc_measure_copy_bandwidth": (C.c_int, [C.c_size_t, C.c_int, c_double_p]),
+    "hcl_node_counts": (C.c_int, [VP, c_long_p]),
     "hc_debug_ibm_per_vertex": (C.c_int, [C.c_int]),
     "hc_debug_force_plane_padding": (C.c_int, [C.c_int]),
     "hcl_create": (C.c_int, [C.POINTER(VP), C.c_int, C.c_int, C.c_int, c_int_p, C.c_double, C.c_int, C.c_int, C.c_int]),
@@ -75,6 +94,7 @@ SIGNATURES = {
     "hcp_celltype_sizes": (C.c_int, [VP, c_int_p]),
     "hcp_celltype_tables": (C.c_int, [VP, c_double_p, c_long_p, c_long_p, c_double_p, c_double_p, c_double_p,
                                       c_long_p, c_double_p, c_double_p]),
+    "hcp_celltype_tables2": (C.c_int, [VP, c_long_p, c_long_p, c_long_p, c_double_p, c_int_p]),
     "hcp_create": (C.c_int, [C.POINTER(VP), VP, C.POINTER(Params)]),
     "hcp_destroy": (C.c_int, [VP]),
     "hcp_add_type": (C.c_int, [VP, VP, C.c_int, c_int_p]),

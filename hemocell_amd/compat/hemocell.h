@@ -200,22 +200,95 @@ struct ProfilerView {
   void outputStatistics() { printStatistics(); }
   void start() { hc_profile_reset(); hc_profile_enable(1); }
 };
-struct Global { ProfilerView statistics; bool cellsDeletedInfo = false; };
+struct Global {   // config/config.h:80-96 (ConfigValues) plus this rank's place in the run
+  ProfilerView statistics; bool cellsDeletedInfo = false; bool hemoCellInitialized = false;
+  int rank = 0, world = 1;
+};
 static Global global;
 
 class HemoCell;
 class HemoCellFields;
 class HemoCellField;
+class HemoCellParticleField;
+template <typename U> struct CEPAC_DESCRIPTOR_T { enum { d = 3, q = 19 }; };
+#define CEPAC_DESCRIPTOR hemo::CEPAC_DESCRIPTOR_T   // config/constant_defaults.h:62-65 (only named in signatures here)
 
-// ------------------------------------------------------------------ mechanics: the plugin classes of hemocell.h:122-128
-struct MeshMetricsView { T volume = 0, surface = 0; T getVolume() const { return volume; } T getSurface() const { return surface; } };
+// ------------------------------------------------------------------ core/hemoCellParticle.h:38-187
+// The plugin-facing view of one membrane vertex.  On this back end the vertices live on the GPU as structure-of-arrays;
+// HemoCellParticleField::particles is filled from them on demand in the reference's own 120-byte record.
+class HemoCellParticle {
+ public:
+  struct serializeValues_t {
+    hemo::Array<T, 3> v, position, force, force_repulsion;
+    plint cellId; uint16_t vertexId; unsigned int restime; unsigned char celltype;
+  };
+  serializeValues_t sv;
+  hemo::Array<T, 3> force_total;
+  plint tag = 0;
+  hemo::Array<T, 3> *force_volume = &sv.force, *force_bending = &sv.force, *force_link = &sv.force, *force_area = &sv.force,
+                    *force_visc = &sv.force, *force_inner_link = &sv.force;
+  HemoCellParticle() { std::memset(&sv, 0, sizeof(sv)); }
+  HemoCellParticle(const serializeValues_t &sv_) : sv(sv_) {}
+  HemoCellParticle(hemo::Array<T, 3> position_, plint cellId_, plint vertexId_, pluint celltype_) {
+    std::memset(&sv, 0, sizeof(sv)); sv.position = position_; sv.cellId = cellId_; sv.vertexId = (uint16_t)vertexId_; sv.celltype = (unsigned char)celltype_;
+  }
+  HemoCellParticle(const HemoCellParticle &o) : sv(o.sv), force_total(o.force_total), tag(o.tag) {}   // force pointers repoint to the copy's own sv.force
+  HemoCellParticle &operator=(const HemoCellParticle &o) { sv = o.sv; force_total = o.force_total; tag = o.tag; return *this; }
+  void repoint_force_vectors() { force_volume = force_bending = force_link = force_area = force_visc = force_inner_link = &sv.force; }
+  void advance() { for (int d = 0; d < 3; d++) sv.position[d] += sv.v[d]; }   // core/hemoCellParticle.h:188-203 (Euler)
+  plint getTag() const { return tag; }
+  void setTag(plint t) { tag = t; }
+};
+static_assert(sizeof(HemoCellParticle::serializeValues_t) == 120, "serializeValues_t is the 120-byte record of the C ABI (hcp_download_records)");
 
+// core/immersedBoundaryMethod.h:62: the default IBM kernel.  On this back end the phi2 stencil is evaluated inside the HIP
+// kernels; the function only exists so that HemoCellField::kernelMethod has its reference default and a driver that
+// installs another kernel can be recognised (and refused).
+inline void interpolationCoefficientsPhi2(plb::BlockLattice3D<T, DESCRIPTOR> &, HemoCellParticle &) {
+  std::cerr << "(HemoCell) (GPU backend) interpolationCoefficientsPhi2 runs on the device (csrc/ibm.hip); it cannot be called on the host" << std::endl;
+  std::exit(1);
+}
+
+// ------------------------------------------------------------------ mechanics/commonCellConstants.h:38-85
+class CommonCellConstants {
+ public:
+  static CommonCellConstants CommonCellConstantsConstructor(HemoCellField &, Config &modelCfg_);
+  HemoCellField *cellFieldPtr = nullptr;
+  std::vector<hemo::Array<plint, 3>> triangle_list;
+  std::vector<hemo::Array<plint, 2>> edge_list;
+  std::vector<T> edge_length_eq_list, edge_angle_eq_list, surface_patch_center_dist_eq_list;
+  std::vector<hemo::Array<plint, 2>> edge_bending_triangles_list, edge_bending_triangles_outer_points;
+  std::vector<T> triangle_area_eq_list;
+  std::vector<hemo::Array<plint, 6>> vertex_vertexes, vertex_edges;
+  std::vector<hemo::Array<signed int, 6>> vertex_edges_sign;
+  std::vector<unsigned int> vertex_n_vertexes;
+  T volume_eq = 0, area_mean_eq = 0, edge_mean_eq = 0, angle_mean_eq = 0;
+  std::vector<hemo::Array<plint, 2>> inner_edge_list;
+  std::vector<T> inner_edge_length_eq_list;
+};
+
+// ------------------------------------------------------------------ mechanics/cellMechanics.h:36-101: the plugin base class
+// A model the GPU evaluates (RbcHighOrderModel, PltSimpleModel below) reports onDevice(); any other subclass compiles
+// against the reference's interface unchanged and is refused by addCellType with the reference's log + exit(1), because
+// its ParticleMechanics is host code working on HemoCellParticle pointers that this back end never materialises per step.
 class CellMechanics {
  public:
+  const CommonCellConstants cellConstants;
+  Config &cfg;
+  CellMechanics(HemoCellField &cellfield, Config &modelCfg_) : cellConstants(CommonCellConstants::CommonCellConstantsConstructor(cellfield, modelCfg_)), cfg(modelCfg_) {}
   virtual ~CellMechanics() {}
+  virtual void ParticleMechanics(std::map<int, std::vector<HemoCellParticle *>> &, const std::map<int, bool> &, pluint ctype) = 0;
   virtual void statistics() = 0;
-  T k_volume = 0, k_area = 0, k_link = 0, k_bend = 0, eta_m = 0;
+  virtual void solidifyMechanics(const std::map<int, std::vector<int>> &, std::vector<HemoCellParticle> &, plb::BlockLattice3D<T, DESCRIPTOR> *,
+                                 plb::BlockLattice3D<T, CEPAC_DESCRIPTOR> *, pluint, HemoCellParticleField &) {}
+  virtual bool onDevice() const { return false; }   // this back end's extension
+  T calculate_kLink(Config &c, plb::MeshMetrics<T> &) { return c["MaterialModel"]["kLink"].read<T>() * Parameters::kBT_lbm / (7.5e-9 / Parameters::dx); }
+  T calculate_kBend(Config &c, plb::MeshMetrics<T> &) { return c["MaterialModel"]["kBend"].read<T>() * Parameters::kBT_lbm / (5e-7 / Parameters::dx); }
+  T calculate_kVolume(Config &c, plb::MeshMetrics<T> &) { return c["MaterialModel"]["kVolume"].read<T>() * (1280.0 / cellConstants.triangle_list.size()) * Parameters::kBT_lbm / (5e-7 / Parameters::dx); }
+  T calculate_kArea(Config &c, plb::MeshMetrics<T> &) { return c["MaterialModel"]["kArea"].read<T>() * (1280.0 / cellConstants.triangle_list.size()) * Parameters::kBT_lbm / (5e-7 / Parameters::dx); }
+  T calculate_etaM(Config &c) { return c["MaterialModel"]["eta_m"].read<T>() * Parameters::dx / Parameters::dt / Parameters::df; }
 };
+typedef plb::MeshMetrics<T> MeshMetricsView;
 
 class HemoCellField {
  public:
@@ -225,8 +298,11 @@ class HemoCellField {
   T minimumDistanceFromSolid = 0;   // micrometres.  core/hemoCellField.h:64 declares it unsigned int (0.5 -> 0); the fraction is kept here
                                     // because only then does examples/pipeflow keep the 42 cells the reference's tests assert
   int numVertex = 0, numTriangles = 0;
-  MeshMetricsView *meshmetric = nullptr;
+  plb::MeshMetrics<T> *meshmetric = nullptr;
   CellMechanics *mechanics = nullptr;
+  void (*kernelMethod)(plb::BlockLattice3D<T, DESCRIPTOR> &, HemoCellParticle &) = interpolationCoefficientsPhi2;   // core/hemoCellField.h:67
+  vector<hemo::Array<plint, 3>> triangle_list;
+  int device_model = -1;   // HC_MODEL_* the device type was built for
   hc_celltype *dev = nullptr;
   vector<double> vertices; vector<long> triangles; vector<long> innerEdges;
   HemoCellFields *cellFields = nullptr;
@@ -242,14 +318,24 @@ class HemoCellField {
   void create_device_type(int model);
 };
 
+// selects the device model before the CellMechanics base builds the tables
 template <int MODEL>
-class DeviceMechanics : public CellMechanics {
+struct DeviceModelTag { explicit DeviceModelTag(HemoCellField &f) { f.device_model = MODEL; } };
+
+template <int MODEL>
+class DeviceMechanics : private DeviceModelTag<MODEL>, public CellMechanics {
  public:
-  DeviceMechanics(Config &, HemoCellField &field) : cellField(field) {
-    field.create_device_type(MODEL);
+  DeviceMechanics(Config &modelCfg_, HemoCellField &field) : DeviceModelTag<MODEL>(field), CellMechanics(field, modelCfg_), cellField(field) {
     double sc[9];
     hc_check(hcp_celltype_tables(field.dev, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sc), "hcp_celltype_tables");
     k_volume = sc[4]; k_area = sc[5]; k_link = sc[6]; k_bend = sc[7]; eta_m = sc[8];
+  }
+  bool onDevice() const override { return true; }
+  // mechanics/rbcHighOrderModel.cpp:38-207 / mechanics/pltSimpleModel.cpp:44-208 are evaluated by mechanics_kernel<MODEL>
+  // (csrc/mechanics.hip) through hcp_mechanics; nothing ever calls the host signature
+  void ParticleMechanics(std::map<int, std::vector<HemoCellParticle *>> &, const std::map<int, bool> &, pluint) override {
+    hlog << "(HemoCell) (GPU backend) " << cellField.name << ": ParticleMechanics is evaluated on the device by HemoCell::iterate(); the host entry point is not available" << endl;
+    std::exit(1);
   }
   void statistics() override {   // mechanics/rbcHighOrderModel.cpp:209-216
     hlog << "(Cell-mechanics model) parameters for " << cellField.name << " cellfield" << endl;
@@ -257,14 +343,56 @@ class DeviceMechanics : public CellMechanics {
          << "\t k_volume: " << k_volume << endl << "\t eta_m:    " << eta_m << endl;
   }
   HemoCellField &cellField;
+  T k_volume = 0, k_area = 0, k_link = 0, k_bend = 0, eta_m = 0;
 };
 typedef DeviceMechanics<HC_MODEL_RBC_HO> RbcHighOrderModel;   // mechanics/rbcHighOrderModel.h
 typedef DeviceMechanics<HC_MODEL_PLT_SIMPLE> PltSimpleModel;  // mechanics/pltSimpleModel.h
 
+// ------------------------------------------------------------------ core/hemoCellParticleField.h:39-207
+// The reference keeps std::vector<HemoCellParticle> per atomic block; here the vertices live on the GPU and this object is
+// a host VIEW of this rank's block: refresh() fills `particles` from the device in the reference's record
+// (hcp_download_records), the lookup maps are derived from it as the reference derives them (update_ppc / update_lpc,
+// core/hemoCellParticleField.cpp:395-467), upload() hands edited records back.
+class HemoCellParticleField {
+ public:
+  explicit HemoCellParticleField(HemoCellFields &f) : fields(f) {}
+  vector<HemoCellParticle> particles;
+  plb::Box3D localDomain, boundingBox;
+  plb::BlockLattice3D<T, DESCRIPTOR> *atomicLattice = nullptr;
+  pluint atomicBlockId = 0, envelopeSize = 0;
+  static HemoCellFields *&cellFieldsRef() { static HemoCellFields *p = nullptr; return p; }
+  pluint getsize() { refresh(); return particles.size(); }
+  plb::Box3D &getBoundingBox() { return boundingBox; }
+  inline void refresh();
+  inline void upload();
+  inline int deleteIncompleteCells(bool verbose = true);
+  const map<int, vector<int>> &get_particles_per_cell() { refresh(); return _particles_per_cell; }
+  const map<int, bool> &get_lpc() { refresh(); return _lpc; }
+  const vector<vector<unsigned int>> &get_particles_per_type() { refresh(); return _particles_per_type; }
+  bool isContainedABS(const hemo::Array<T, 3> &pos, const plb::Box3D &box) const {
+    return (pos[0] > box.x0 - 0.5) && (pos[0] <= box.x1 + 0.5) && (pos[1] > box.y0 - 0.5) && (pos[1] <= box.y1 + 0.5) && (pos[2] > box.z0 - 0.5) && (pos[2] <= box.z1 + 0.5);
+  }
+  void invalidate() { fresh_iter = -1; }
+ private:
+  HemoCellFields &fields;
+  long fresh_iter = -1;
+  map<int, vector<int>> _particles_per_cell; map<int, bool> _lpc; vector<vector<unsigned int>> _particles_per_type;
+};
+}  // namespace hemo
+namespace plb {
+template <class PF>
+struct MultiParticleField3D {   // particles/multiParticleField3D.h: one atomic block per rank here
+  explicit MultiParticleField3D(PF *p) : pf(p) {}
+  PF &getComponent(plint) { return *pf; }
+  PF *pf;
+};
+}  // namespace plb
+namespace hemo {
+
 class HemoCellFields {
  public:
-  explicit HemoCellFields(HemoCell &h) : hemocell(h) {}
-  ~HemoCellFields() { for (auto *f : cellFields) delete f; if (dev) hcp_destroy(dev); }
+  explicit HemoCellFields(HemoCell &h) : hemocell(h), particleField(*this), immersedParticles(new plb::MultiParticleField3D<HemoCellParticleField>(&particleField)) { HemoCellParticleField::cellFieldsRef() = this; }
+  ~HemoCellFields() { for (auto *f : cellFields) delete f; if (dev) hcp_destroy(dev); delete immersedParticles; }
   HemoCellField *operator[](unsigned int i) { return cellFields[i]; }
   HemoCellField *operator[](const string &name) {
     for (auto *f : cellFields) if (f->name == name) return f;
@@ -285,6 +413,15 @@ class HemoCellFields {
   unsigned int particleVelocityUpdateTimescale = 1;
   hc_cells *dev = nullptr;
   bool types_bound = false;
+  HemoCellParticleField particleField;
+  plb::MultiParticleField3D<HemoCellParticleField> *immersedParticles;   // core/hemoCellFields.h:161
+  // core/hemoCellFields.h:103-158: the phase methods drivers may call one by one
+  inline void spreadParticleForce();
+  inline void interpolateFluidVelocity();
+  inline void advanceParticles();
+  inline void applyConstitutiveModel(bool forced = false);
+  inline void deleteIncompleteCells(bool verbose = true);
+  inline void syncEnvelopes() {}   // part of the slab schedule inside hc_iterate (csrc/slab.hip)
 };
 
 // ------------------------------------------------------------------ hemocell.h:68-253
@@ -293,15 +430,27 @@ class HemoCell {
   enum class MPIHandle { Internal, External };
   HemoCell(char *configFileName, int argc, char *argv[]) : HemoCell(configFileName, argc, argv, MPIHandle::Internal) {}
   HemoCell(char *configFileName, int, char *[], MPIHandle) {
-    hc_check(hc_init(0), "hc_init");       // replaces plb::plbInit (core/hemoCell.cpp:80-86)
+    // replaces plb::plbInit / MPI_Init (core/hemoCell.cpp:80-86): a run started as several processes (mpirun-style
+    // RANK / WORLD_SIZE / LOCAL_RANK or OMPI_* / PMI_* variables) becomes one x-slab per process and GPU
+    if (global.hemoCellInitialized) { std::cerr << "(HemoCell) only one HemoCell per process (core/hemoCell.cpp:75-79)" << std::endl; std::exit(1); }
+    global.hemoCellInitialized = true;
+    hc_check(hc_comm_init_env(), "hc_comm_init_env");
+    int tr = 0; hc_comm_info(&global.rank, &global.world, &tr);
+    if (global.world == 1) hc_check(hc_init(0), "hc_init");
     cfg = new Config(configFileName);
     configFile = configFileName;
     try { outDir = (*cfg)["parameters"]["outputDirectory"].read<string>(); } catch (std::invalid_argument &) { outDir = "tmp"; }
-    mkdir(outDir.c_str(), 0755); mkdir((outDir + "/log").c_str(), 0755); mkdir((outDir + "/csv").c_str(), 0755);
-    hlog_instance().file.open((outDir + "/log/logfile").c_str());
-    hlogfile_instance().file.open((outDir + "/log/logfile.detail").c_str());
+    try { global.cellsDeletedInfo = (*cfg)["verbose"]["cellsDeletedInfo"].read<int>() != 0; } catch (std::invalid_argument &) {}   // config/config.cpp:180
+    if (global.rank == 0) {
+      mkdir(outDir.c_str(), 0755); mkdir((outDir + "/log").c_str(), 0755); mkdir((outDir + "/csv").c_str(), 0755);
+      hlog_instance().file.open((outDir + "/log/logfile").c_str());
+      hlogfile_instance().file.open((outDir + "/log/logfile.detail").c_str());
+    } else hlog_instance().to_stdout = false;   // the log is rank 0's (config/logfile.h)
+    hc_comm_barrier();
+    hlog << "(HemoCell) (Config) reading " << configFileName << endl;
+    if (global.world > 1) hlog << "(HemoCell) (GPU backend) " << global.world << " ranks: one x-slab per rank and GPU, " << (tr == HC_TRANSPORT_RCCL ? "RCCL point-to-point" : "host-staged (ranks share a GPU)") << " neighbour exchange" << endl;
   }
-  ~HemoCell() { delete cellfields; delete lattice; delete cfg; }   // core/hemoCell.cpp:97-127: the facade owns the driver's lattice
+  ~HemoCell() { delete cellfields; delete lattice; delete cfg; hc_comm_finalize(); global.hemoCellInitialized = false; }   // core/hemoCell.cpp:97-127: the facade owns the driver's lattice
 
   void latticeEquilibrium(T rho, hemo::Array<T, 3> vel) { lattice->eq_rho = rho; for (int d = 0; d < 3; d++) lattice->eq_u[d] = vel[d]; lattice->dirty_layout = true; }
   void initializeCellfield() { cellfields = new HemoCellFields(*this); }
@@ -311,6 +460,13 @@ class HemoCell {
     HemoCellField *cellfield = cellfields->addCellType(name, constructType);
     Mechanics *mechanics = new Mechanics(*cellfield->materialCfg, *cellfield);
     cellfield->mechanics = mechanics;
+    if (!mechanics->onDevice()) {
+      // the reference would call mechanics->ParticleMechanics(map<int, vector<HemoCellParticle*>>&, ...) on the host every
+      // material step (core/hemoCellParticleField.cpp:669); this back end has no host particle objects in the loop
+      hlog << "(HemoCell) (AddCellType) the mechanics model given for \"" << name << "\" is host code (it overrides CellMechanics::ParticleMechanics); "
+           << "the GPU back end evaluates RbcHighOrderModel and PltSimpleModel on the device and cannot run it. Exiting." << endl;
+      std::exit(1);
+    }
     cellfield->statistics();
   }
   void setOutputs(string name, vector<int> outputs) { (*cellfields)[name]->desiredOutputVariables = outputs; }
@@ -351,8 +507,11 @@ class HemoCell {
     if (boundaryRepulsionEnabled && !boundaryRepulsionPushed) { hc_check(hcp_set_boundary_repulsion(c, boundaryRepulsionConstant_, boundaryRepulsionCutoff_, (int)boundaryRepulsionTimescale), "hcp_set_boundary_repulsion"); boundaryRepulsionPushed = true; }
     if (repulsionEnabled && !repulsionPushed) { hc_check(hcp_set_repulsion(c, repulsionConstant_, repulsionCutoff_, (int)repulsionTimescale), "hcp_set_repulsion"); repulsionPushed = true; }
     long it = iter;
-    hc_check(hc_iterate(lattice->device(), c, &it, 1, (int)cellfields->particleVelocityUpdateTimescale, /*force_limit=*/1, /*deletion check=*/1), "iterate");
+    const bool particle_step = iter % cellfields->particleVelocityUpdateTimescale == 0;
+    hc_check(hc_iterate(lattice->device(), c, &it, 1, (int)cellfields->particleVelocityUpdateTimescale, /*force_limit=*/1, /*compaction look-up cadence=*/1), "iterate");
+    if (global.cellsDeletedInfo && particle_step) cellfields->deleteIncompleteCells(true);   // core/hemoCell.cpp:360-363
     lattice->mark_stepped();
+    cellfields->particleField.invalidate();
     iter = (unsigned int)it;
   }
 
@@ -394,15 +553,59 @@ inline void HemoCellField::create_device_type(int model) {
   vertices.resize(3 * (size_t)sz[0]); triangles.resize(3 * (size_t)sz[1]);
   vector<double> area((size_t)sz[1]); double sc[9];
   hc_check(hcp_celltype_tables(dev, vertices.data(), triangles.data(), nullptr, nullptr, nullptr, area.data(), nullptr, nullptr, sc), "hcp_celltype_tables");
-  meshmetric = new MeshMetricsView();
-  meshmetric->volume = sc[0];
+  triangle_list.resize((size_t)sz[1]);
+  for (int t = 0; t < sz[1]; t++) for (int k = 0; k < 3; k++) triangle_list[(size_t)t][(size_t)k] = triangles[3 * (size_t)t + (size_t)k];
+  meshmetric = new plb::MeshMetrics<T>();
+  meshmetric->volume = sc[0]; meshmetric->meanLength = sc[2]; meshmetric->numVertices = sz[0]; meshmetric->numTriangles = sz[1];
   for (double a : area) meshmetric->surface += a;
 }
 
+// mechanics/commonCellConstants.cpp:70-409: the tables are built by the library (csrc/mesh.cpp) together with the mesh;
+// this copies them into the reference's container for models that read them
+inline CommonCellConstants CommonCellConstants::CommonCellConstantsConstructor(HemoCellField &field, Config &) {
+  if (!field.dev) field.create_device_type(field.device_model >= 0 ? field.device_model : HC_MODEL_RBC_HO);   // a host model still gets the mesh and its constants
+  CommonCellConstants c; c.cellFieldPtr = &field;
+  int sz[4]; hcp_celltype_sizes(field.dev, sz);
+  const size_t nv = (size_t)sz[0], nt = (size_t)sz[1], ne = (size_t)sz[2], nie = (size_t)sz[3];
+  vector<long> tri(3 * nt), edge(2 * ne), ring(6 * nv), ebt(2 * ne), ebo(2 * ne), ie(2 * nie);
+  vector<int> nring(nv);
+  c.edge_length_eq_list.resize(ne); c.edge_angle_eq_list.resize(ne); c.triangle_area_eq_list.resize(nt); c.surface_patch_center_dist_eq_list.resize(nv);
+  c.inner_edge_length_eq_list.resize(nie);
+  double sc[9];
+  hc_check(hcp_celltype_tables(field.dev, nullptr, tri.data(), edge.data(), c.edge_length_eq_list.data(), c.edge_angle_eq_list.data(), c.triangle_area_eq_list.data(),
+                               ring.data(), c.surface_patch_center_dist_eq_list.data(), sc), "hcp_celltype_tables");
+  hc_check(hcp_celltype_tables2(field.dev, ebt.data(), ebo.data(), ie.data(), c.inner_edge_length_eq_list.data(), nring.data()), "hcp_celltype_tables2");
+  c.triangle_list.resize(nt); for (size_t t = 0; t < nt; t++) for (size_t k = 0; k < 3; k++) c.triangle_list[t][k] = tri[3 * t + k];
+  c.edge_list.resize(ne); c.edge_bending_triangles_list.resize(ne); c.edge_bending_triangles_outer_points.resize(ne);
+  for (size_t e = 0; e < ne; e++) for (size_t k = 0; k < 2; k++) { c.edge_list[e][k] = edge[2 * e + k]; c.edge_bending_triangles_list[e][k] = ebt[2 * e + k]; c.edge_bending_triangles_outer_points[e][k] = ebo[2 * e + k]; }
+  c.inner_edge_list.resize(nie); for (size_t e = 0; e < nie; e++) for (size_t k = 0; k < 2; k++) c.inner_edge_list[e][k] = ie[2 * e + k];
+  c.vertex_vertexes.resize(nv); c.vertex_n_vertexes.resize(nv);
+  for (size_t i = 0; i < nv; i++) { for (size_t k = 0; k < 6; k++) c.vertex_vertexes[i][k] = ring[6 * i + k]; c.vertex_n_vertexes[i] = (unsigned int)nring[i]; }
+  // vertex_edges / vertex_edges_sign (mechanics/commonCellConstants.cpp:283-310): the edge towards each ring neighbour and whether this vertex is its first end
+  c.vertex_edges.assign(nv, hemo::Array<plint, 6>()); c.vertex_edges_sign.assign(nv, hemo::Array<signed int, 6>());
+  for (size_t i = 0; i < nv; i++) for (size_t k = 0; k < 6; k++) {
+    c.vertex_edges[i][k] = -1; c.vertex_edges_sign[i][k] = 0;
+    const plint nb = c.vertex_vertexes[i][k];
+    if (nb < 0) continue;
+    for (size_t e = 0; e < ne; e++) {
+      if (c.edge_list[e][0] == (plint)i && c.edge_list[e][1] == nb) { c.vertex_edges[i][k] = (plint)e; c.vertex_edges_sign[i][k] = 1; break; }
+      if (c.edge_list[e][1] == (plint)i && c.edge_list[e][0] == nb) { c.vertex_edges[i][k] = (plint)e; c.vertex_edges_sign[i][k] = -1; break; }
+    }
+  }
+  c.volume_eq = sc[0]; c.area_mean_eq = sc[1]; c.edge_mean_eq = sc[2]; c.angle_mean_eq = sc[3];
+  return c;
+}
+
 inline hc_cells *HemoCellFields::device() {
-  if (!dev) hc_check(hcp_create(&dev, hemocell.lattice->device(), &Parameters::raw()), "hcp_create");
+  if (!dev) { hc_check(hcp_create(&dev, hemocell.lattice->device(), &Parameters::raw()), "hcp_create"); hemocell.lattice->cells_bound = true; }
   if (!types_bound) {
-    for (auto *f : cellFields) hc_check(hcp_add_type(dev, f->dev, (int)f->timescale, nullptr), "hcp_add_type");
+    for (auto *f : cellFields) {
+      if (f->kernelMethod != interpolationCoefficientsPhi2) {   // core/hemoCellField.h:67: a user IBM kernel is host code
+        hlog << "(HemoCell) (GPU backend) cell type " << f->name << " installs its own IBM kernelMethod; only interpolationCoefficientsPhi2 (core/immersedBoundaryMethod.h:62-138) runs on the device. Exiting." << endl;
+        std::exit(1);
+      }
+      hc_check(hcp_add_type(dev, f->dev, (int)f->timescale, nullptr), "hcp_add_type");
+    }
     types_bound = true;
   }
   return dev;
@@ -414,11 +617,12 @@ inline void HemoCell::loadParticles() {
   int total = 0, cellid = 0;
   for (unsigned int j = 0; j < cellfields->size(); j++) { std::ifstream f(((*cellfields)[j]->name + ".pos").c_str()); int n = 0; if (f.is_open()) f >> n; total += n; }
   cellfields->number_of_cells = total;
+  vector<int> placed_per_type;
   const T posRatio = 1e-6 / Parameters::dx;
   for (unsigned int j = 0; j < cellfields->size(); j++) {
     HemoCellField *field = (*cellfields)[j];
     std::ifstream f((field->name + ".pos").c_str());
-    if (!f.is_open()) { std::cout << "*** WARNING! particle positions input file " << field->name << ".pos does not exist!" << std::endl; continue; }
+    if (!f.is_open()) { if (global.rank == 0) std::cout << "*** WARNING! particle positions input file " << field->name << ".pos does not exist!" << std::endl; placed_per_type.push_back(0); continue; }
     int n = 0; f >> n;
     hlog << "(readPositionsBloodCells) Particle count in file (" << field->name << "): " << n << "." << endl;
     int placed_n = 0;
@@ -448,8 +652,15 @@ inline void HemoCell::loadParticles() {
       hc_check(hcp_add_cell(c, (int)j, e.id, e.p, e.a, (double)field->minimumDistanceFromSolid, &placed), "hcp_add_cell");
       placed_n += placed;
     }
-    hlog << "(readPositionsBloodCells) " << placed_n << " complete " << field->name << " cells placed." << endl;
+    placed_per_type.push_back(placed_n);
   }
+  if (global.world > 1) {   // every rank offered every cell; agree on the rejected ones and count the distinct cells
+    vector<long> g(cellfields->size() + 1, 0);
+    hc_check(hcp_slab_sync_placement(c, g.data()), "hcp_slab_sync_placement");
+    for (size_t t = 0; t < placed_per_type.size(); t++) placed_per_type[t] = (int)g[t];
+  }
+  for (unsigned int j = 0; j < cellfields->size() && j < placed_per_type.size(); j++)
+    hlog << "(readPositionsBloodCells) " << placed_per_type[j] << " complete " << (*cellfields)[j]->name << " cells placed." << endl;
   long it = iter;   // forces of the initial configuration, as the first applyConstitutiveModel would give them
   hc_check(hcp_mechanics(c, it, 1), "hcp_mechanics");
 }
@@ -527,6 +738,15 @@ struct CellInformation {
 };
 struct CellInformationFunctionals {
   static map<int, CellInformation> &info() { static map<int, CellInformation> m; return m; }
+  // helper/cellInfo.cpp:97: a cell is counted / reported by the rank whose domain holds its centre
+  static bool centre_local(HemoCell *h, const double *centroid) {
+    if (global.world == 1) return true;
+    const auto *L = h->lattice;
+    double cx = centroid[0];
+    if (L->per.p[0]) cx -= (double)L->nx * std::floor((cx + 0.5) / (double)L->nx);   // copies across the seam are unwrapped images
+    const double g = std::floor(cx + 0.5);
+    return g >= (double)L->x0 && g < (double)(L->x0 + L->nxl);
+  }
   static void fill(HemoCell *h, bool vol, bool area, bool pos, bool bbox, bool stretch) {
     hc_cells *c = h->cellfields->device();
     long nvt = 0, nct = 0; hcp_counts(c, &nvt, &nct, nullptr);
@@ -540,8 +760,9 @@ struct CellInformationFunctionals {
       hc_check(hcp_cell_info(c, (int)t, V.data(), A.data(), B.data(), P.data()), "hcp_cell_info");
       const int nv = (*h->cellfields)[t]->numVertex;
       for (long k = 0; k < nc; k++) {
+        if (!centre_local(h, &P[3 * (size_t)k])) continue;   // the other holder reports it
         CellInformation &ci = info()[(int)ids[(size_t)(first_cell + k)]];
-        ci.cellType = t; ci.base_cell_id = ids[(size_t)(first_cell + k)];
+        ci.cellType = t; ci.base_cell_id = ids[(size_t)(first_cell + k)]; ci.blockId = global.rank;
         if (vol) ci.volume = V[(size_t)k];
         if (area) ci.area = A[(size_t)k];
         if (pos) for (int d = 0; d < 3; d++) ci.position[d] = P[3 * (size_t)k + d];
@@ -565,18 +786,40 @@ struct CellInformationFunctionals {
   static void calculateCellStretch(HemoCell *h) { fill(h, false, false, false, false, true); }
   static void calculateCellInformation(HemoCell *h) { fill(h, true, true, true, true, false); }
   static void clear_list() { info().clear(); }
-  static pluint getTotalNumberOfCells(HemoCell *h) { long nc = 0; hcp_counts(h->cellfields->device(), nullptr, &nc, nullptr); return (pluint)nc; }
-  static pluint getNumberOfCellsFromType(HemoCell *h, string type) { long nc = 0; hcp_type_range(h->cellfields->device(), (int)(*h->cellfields)[type]->ctype, nullptr, &nc); return (pluint)nc; }
+  // helper/cellInfo.cpp:324-365: centre-local cells of every rank, summed (HemoCellGatheringFunctional)
+  static vector<double> counts_per_type(HemoCell *h) {
+    hc_cells *c = h->cellfields->device();
+    vector<double> n(h->cellfields->size(), 0.0);
+    for (unsigned int t = 0; t < h->cellfields->size(); t++) {
+      long fv = 0, nc = 0; hcp_type_range(c, (int)t, &fv, &nc);
+      if (global.world == 1 || nc == 0) { n[t] = (double)nc; continue; }
+      vector<double> V((size_t)nc), A((size_t)nc), B(6 * (size_t)nc), P(3 * (size_t)nc);
+      hc_check(hcp_cell_info(c, (int)t, V.data(), A.data(), B.data(), P.data()), "hcp_cell_info");
+      for (long k = 0; k < nc; k++) n[t] += centre_local(h, &P[3 * (size_t)k]) ? 1.0 : 0.0;
+    }
+    if (global.world > 1 && !n.empty()) hc_check(hc_comm_allreduce(n.data(), (int)n.size(), 0), "hc_comm_allreduce");
+    return n;
+  }
+  static pluint getTotalNumberOfCells(HemoCell *h) { double s = 0; for (double v : counts_per_type(h)) s += v; return (pluint)(s + 0.5); }
+  static pluint getNumberOfCellsFromType(HemoCell *h, string type) { return (pluint)(counts_per_type(h)[(*h->cellfields)[type]->ctype] + 0.5); }
 };
 #define info_per_cell info()
 
 // ------------------------------------------------------------------ helper/fluidInfo.h, helper/particleInfo.h
 struct FluidStatistics { T min = 0, max = 0, avg = 0; pluint ncells = 0; };
+// {min, max, sum}, n over all ranks (the reference gathers per-block results, helper/fluidInfo.cpp:98-118)
+inline void reduce_stats(double o[3], long &n) {
+  if (global.world == 1) return;
+  double mn = n ? o[0] : 1e300, mx = n ? o[1] : -1e300, sm[2] = {o[2], (double)n};
+  hc_check(hc_comm_allreduce(&mn, 1, 1), "hc_comm_allreduce"); hc_check(hc_comm_allreduce(&mx, 1, 2), "hc_comm_allreduce"); hc_check(hc_comm_allreduce(sm, 2, 0), "hc_comm_allreduce");
+  n = (long)(sm[1] + 0.5); o[0] = n ? mn : 0.0; o[1] = n ? mx : 0.0; o[2] = sm[0];
+}
 struct FluidInfo {
   // helper/fluidInfo.cpp:33-118: device reductions (hcl_fluid_stats), folded deterministically
   static FluidStatistics stat(HemoCell *h, int what) {
     double o[3]; long n = 0;
     hc_check(hcl_fluid_stats(h->lattice->device(), what, o, &n), "hcl_fluid_stats");
+    reduce_stats(o, n);
     FluidStatistics s; s.min = o[0]; s.max = o[1]; s.ncells = (pluint)n; s.avg = n ? o[2] / (double)n : 0;
     return s;
   }
@@ -589,6 +832,7 @@ struct ParticleInfo {
   static ParticleStatistics stat(HemoCell *h, int what) {
     double o[3]; long n = 0;
     hc_check(hcp_vertex_stats(h->cellfields->device(), what, o, &n), "hcp_vertex_stats");
+    reduce_stats(o, n);
     ParticleStatistics s; s.min = o[0]; s.max = o[1]; s.ncells = (pluint)n; s.avg = n ? o[2] / (double)n : 0;
     return s;
   }
@@ -600,16 +844,38 @@ struct ParticleInfo {
 inline void writeCellInfo_CSV(HemoCell &h) {
   CellInformationFunctionals::clear_list();
   CellInformationFunctionals::calculateCellInformation(&h);
-  for (unsigned int t = 0; t < h.cellfields->size(); t++) {
-    char it[32]; std::snprintf(it, sizeof(it), "%012u", h.iter);
-    std::ofstream f((h.outDir + "/csv/" + (*h.cellfields)[t]->name + "." + it + ".csv").c_str());
-    f << "X,Y,Z,area,volume,atomic_block,cellId,baseCellId,velocity_x,velocity_y,velocity_z" << std::endl;   // :52
-    for (auto &kv : CellInformationFunctionals::info()) {
-      if (kv.second.cellType != t) continue;
-      const CellInformation &c = kv.second;
-      f << c.position[0] << "," << c.position[1] << "," << c.position[2] << "," << c.area << "," << c.volume << ",0," << kv.first << "," << c.base_cell_id << ",0,0,0" << std::endl;
-    }
+  // every rank holds its centre-local cells; rank 0 gathers and writes (HemoCellGatheringFunctional, :45)
+  struct Row { double v[8]; };   // x y z area volume block cellId type
+  vector<Row> mine;
+  for (auto &kv : CellInformationFunctionals::info()) {
+    const CellInformation &c = kv.second; Row r;
+    const double sx = h.outputInSiUnits ? Parameters::dx : 1.0;
+    r.v[0] = c.position[0] * sx; r.v[1] = c.position[1] * sx; r.v[2] = c.position[2] * sx; r.v[3] = c.area * sx * sx; r.v[4] = c.volume * sx * sx * sx;
+    r.v[5] = (double)c.blockId; r.v[6] = (double)kv.first; r.v[7] = (double)c.cellType;
+    mine.push_back(r);
   }
+  vector<Row> all = mine;
+  if (global.world > 1) {
+    double cnt = (double)mine.size(), mx = cnt;
+    hc_check(hc_comm_allreduce(&mx, 1, 2), "hc_comm_allreduce");
+    const size_t cap = (size_t)mx;
+    vector<Row> padded(cap + 1); padded[0].v[0] = cnt; std::copy(mine.begin(), mine.end(), padded.begin() + 1);
+    vector<Row> gathered((cap + 1) * (size_t)global.world);
+    hc_check(hc_comm_allgather(padded.data(), (cap + 1) * sizeof(Row), gathered.data()), "hc_comm_allgather");
+    all.clear();
+    for (int r = 0; r < global.world; r++) { const Row *b = gathered.data() + (size_t)r * (cap + 1); for (size_t k = 0; k < (size_t)b[0].v[0]; k++) all.push_back(b[1 + k]); }
+    std::stable_sort(all.begin(), all.end(), [](const Row &a, const Row &b) { return a.v[6] < b.v[6]; });
+  }
+  if (global.rank == 0)
+    for (unsigned int t = 0; t < h.cellfields->size(); t++) {
+      char it[32]; std::snprintf(it, sizeof(it), "%012u", h.iter);
+      std::ofstream f((h.outDir + "/csv/" + (*h.cellfields)[t]->name + "." + it + ".csv").c_str());
+      f << "X,Y,Z,area,volume,atomic_block,cellId,baseCellId,velocity_x,velocity_y,velocity_z" << std::endl;   // :52
+      for (const Row &r : all) {
+        if ((unsigned int)r.v[7] != t) continue;
+        f << r.v[0] << "," << r.v[1] << "," << r.v[2] << "," << r.v[3] << "," << r.v[4] << "," << (long)r.v[5] << "," << (long)r.v[6] << "," << (long)r.v[6] << ",0,0,0" << std::endl;
+      }
+    }
   CellInformationFunctionals::clear_list();
 }
 

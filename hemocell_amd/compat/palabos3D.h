@@ -81,6 +81,16 @@ struct BounceBack : Dynamics<U, D> {
 };
 
 struct MultiBlockManagement3D { plint nx = 0, ny = 0, nz = 0, envelope = 1; };
+
+// names that only appear in signatures of the plugin surface (mechanics/cellMechanics.h:45, core/hemoCellField.h:67)
+template <typename U, template <typename> class D>
+struct BlockLattice3D { plint nx = 0, ny = 0, nz = 0; plint getNx() const { return nx; } plint getNy() const { return ny; } plint getNz() const { return nz; } };
+template <typename U>
+struct MeshMetrics {   // offLattice/triangularSurfaceMesh metrics the models read (mechanics/cellMechanics.h:50-78)
+  U volume = 0, surface = 0, meanLength = 0; plint numVertices = 0, numTriangles = 0;
+  U getVolume() const { return volume; } U getSurface() const { return surface; } U getMeanLength() const { return meanLength; }
+  plint getNumVertices() const { return numVertices; } plint getNumTriangles() const { return numTriangles; }
+};
 struct BlockCommunicator3D {};
 struct CombinedStatistics {};
 template <typename U, template <typename> class D> struct MultiCellAccess3D {};
@@ -117,8 +127,9 @@ class VoxelizedDomain3D {
 
 struct Periodicity3D {
   bool p[3] = {false, false, false};
-  void toggleAll(bool v) { p[0] = p[1] = p[2] = v; }
-  void toggle(int axis, bool v) { p[axis] = v; }
+  bool *changed = nullptr;   // set when a toggle really changes something; reading never does
+  void toggleAll(bool v) { for (int a = 0; a < 3; a++) toggle(a, v); }
+  void toggle(int axis, bool v) { if (p[axis] != v) { p[axis] = v; if (changed) *changed = true; } }
   bool get(int axis) const { return p[axis]; }
 };
 
@@ -128,28 +139,37 @@ template <typename U, template <typename> class D>
 class MultiBlockLattice3D {
  public:
   MultiBlockLattice3D(const MultiBlockManagement3D &m, BlockCommunicator3D *, CombinedStatistics *, MultiCellAccess3D<U, D> *, Dynamics<U, D> *background)
-      : nx(m.nx), ny(m.ny), nz(m.nz), omega(background ? background->getOmega() : U(1)), mask((size_t)m.nx * m.ny * m.nz, 0) { delete background; }
+      : nx(m.nx), ny(m.ny), nz(m.nz), omega(background ? background->getOmega() : U(1)), mask((size_t)m.nx * m.ny * m.nz, 0) { delete background; per.changed = &dirty_layout; }
   ~MultiBlockLattice3D() { if (dev) hcl_destroy(dev); }
   Box3D getBoundingBox() const { return Box3D(0, nx - 1, 0, ny - 1, 0, nz - 1); }
   plint getNx() const { return nx; }
   plint getNy() const { return ny; }
   plint getNz() const { return nz; }
   void toggleInternalStatistics(bool) {}
-  Periodicity3D &periodicity() { dirty_layout = true; return per; }
+  Periodicity3D &periodicity() { return per; }
   void initialize() {}
   void collideAndStream() { device(); hc_check(hcl_collide_stream(dev, 1), "collideAndStream"); }
 
   // ---- used by the shims below and by hemo::HemoCell
+  // The device lattice of THIS rank: the whole domain on one GPU, or -- when the run was started as several ranks
+  // (hc_comm_init_env in the HemoCell constructor) -- the x-slab [x0, x0 + nxl) of it, with the planes split as evenly as the
+  // reference's block distribution does along one axis.  The driver keeps describing the global lattice.
   hc_lattice *device() {
     if (dev && !dirty_layout) { if (dirty_force) push_force(); return dev; }
-    if (dev && stepped) { std::cerr << "(HemoCell) (GPU backend) the lattice layout was changed after the first time step" << std::endl; std::exit(1); }
+    if (dev && (stepped || cells_bound)) {
+      std::cerr << "(HemoCell) (GPU backend) the lattice layout (dynamics / periodicity) was changed after " << (stepped ? "the first time step" : "the particles were loaded") << std::endl;
+      std::exit(1);
+    }
     if (dev) { hcl_destroy(dev); dev = nullptr; }
     int pr[3] = {per.p[0], per.p[1], per.p[2]};
-    hc_check(hc_init(0), "hc_init");
-    hc_check(hcl_create(&dev, (int)nx, (int)ny, (int)nz, pr, omega, 0, (int)nx, 1), "hcl_create");
-    std::vector<uint8_t> padded((size_t)(nx + 4) * ny * nz, 1);
-    for (plint x = -2; x < nx + 2; x++) {
-      plint sx = x;
+    int tr = 0;
+    hc_comm_info(&rank, &world, &tr);
+    if (world == 1) hc_check(hc_init(0), "hc_init");
+    x0 = (plint)rank * nx / world; nxl = (plint)(rank + 1) * nx / world - x0;
+    hc_check(hcl_create(&dev, (int)nxl, (int)ny, (int)nz, pr, omega, (int)x0, (int)nx, world), "hcl_create");
+    std::vector<uint8_t> padded((size_t)(nxl + 4) * ny * nz, 1);   // beyond a non-periodic end: wall
+    for (plint x = -2; x < nxl + 2; x++) {
+      plint sx = x0 + x;
       if (sx < 0 || sx >= nx) { if (per.p[0]) sx = ((sx % nx) + nx) % nx; else continue; }
       std::copy(mask.begin() + (size_t)sx * ny * nz, mask.begin() + (size_t)(sx + 1) * ny * nz, padded.begin() + (size_t)(x + 2) * ny * nz);
     }
@@ -179,8 +199,9 @@ class MultiBlockLattice3D {
   Periodicity3D per;
   U eq_rho = 1; U eq_u[3] = {0, 0, 0};
   U body[3] = {0, 0, 0};
-  bool dirty_layout = true, dirty_force = true, stepped = false;
+  bool dirty_layout = true, dirty_force = true, stepped = false, cells_bound = false;
   hc_lattice *dev = nullptr;
+  int rank = 0, world = 1; plint x0 = 0, nxl = 0;   // this rank's slab (valid once device() ran)
 };
 
 // defineDynamics(lattice, flagMatrix, bbox, new BounceBack(1.), flag)   (examples/pipeflow/pipeflow.cpp:73)
@@ -242,10 +263,16 @@ void setBoundaryVelocity(MultiBlockLattice3D<U, D> &l, Box3D b, Array<U, 3> v) {
 
 template <typename U, template <typename> class D>
 std::string getMultiBlockInfo(MultiBlockLattice3D<U, D> &l) {
-  return "Size of the lattice: " + std::to_string(l.nx) + "-by-" + std::to_string(l.ny) + "-by-" + std::to_string(l.nz) + " (one slab on one GPU)";
+  int rank = 0, world = 1, tr = 0; hc_comm_info(&rank, &world, &tr);
+  return "Size of the lattice: " + std::to_string(l.nx) + "-by-" + std::to_string(l.ny) + "-by-" + std::to_string(l.nz) + " (" + std::to_string(world) + " x-slab" + (world > 1 ? "s, one per GPU)" : " on one GPU)");
 }
 
-struct Pcout { template <typename V> Pcout &operator<<(const V &v) { std::cout << v; return *this; } Pcout &operator<<(std::ostream &(*f)(std::ostream &)) { std::cout << f; return *this; } };
+// plb::pcout: rank 0 only
+struct Pcout {
+  static bool main() { int r = 0; hc_comm_info(&r, nullptr, nullptr); return r == 0; }
+  template <typename V> Pcout &operator<<(const V &v) { if (main()) std::cout << v; return *this; }
+  Pcout &operator<<(std::ostream &(*f)(std::ostream &)) { if (main()) std::cout << f; return *this; }
+};
 static Pcout pcout;
 typedef std::ofstream plb_ofstream;
 

@@ -31,7 +31,10 @@ struct hc_cells {
   int timescale[8];
   std::vector<double> hpos[8];   // host staging per type: [ncells*nv][3]
   std::vector<double> hvel[8], hfrc[8];
+  std::vector<double> hrep[8];   // force_repulsion staging (filled only while a repulsion is enabled)
   std::vector<long> hids[8];
+  std::vector<int> htag[8];              // per cell: 0 complete, 2 incomplete (a gone cell never reaches the host staging)
+  std::vector<unsigned char> hdead[8];   // per vertex: 1 = this particle was removed (reference deletion mode)
   bool host_dirty = false;       // host staging newer than device
   long nverts = 0, cap = 0;      // live vertices (all types); allocated vertex capacity
   long ncells[8] = {0};
@@ -39,10 +42,19 @@ struct hc_cells {
   long first[8] = {0};           // first vertex of each type's region on the device
   long cell0[8] = {0};           // first cell slot of each type's region
   double *pos[3] = {nullptr, nullptr, nullptr}, *vel[3] = {nullptr, nullptr, nullptr}, *frc[3] = {nullptr, nullptr, nullptr};
-  int *d_tag = nullptr;          // per-cell deletion tags (all types, slot order)
+  // Deletion lives on the device (core/hemoCellParticleField.cpp:566-588, :304-321 without a host round trip):
+  // d_tag per cell slot: 0 complete, 1 gone (every kernel skips the cell; the slot is reclaimed at the next
+  // compaction), 2 incomplete (the reference's state after removeParticles(1) took single particles out: no
+  // mechanics, forces zeroed at the next material step, the remaining particles are still spread / interpolated /
+  // advanced); d_vdead per vertex: 1 = removed particle.
+  int *d_tag = nullptr;          // [tag_cap] all types, slot order
   long tag_cap = 0;
-  int *h_ntag = nullptr;         // pinned host copy of the tag counter
-  int *d_ntag = nullptr;         // device counter of tagged cells
+  unsigned char *d_vdead = nullptr;   // [cap]
+  int *h_ntag = nullptr;         // pinned host copy of the counters {cells gone and not yet compacted, cells made incomplete}
+  int *d_ntag = nullptr;         // device counters [2]
+  hipEvent_t ntag_ev = nullptr;  // completion of an asynchronous counter read (hc_iterate polls it, never waits)
+  bool ntag_pending = false, maybe_tagged = false;
+  int del_mode = HC_DELETE_PARTICLE;
   int *d_vert_cell = nullptr;    // [cap] cell slot of every vertex
   // vertex-vertex repulsion (core/hemoCellParticleField.cpp:677-743); arrays exist only once it is enabled
   double *rep[3] = {nullptr, nullptr, nullptr};
@@ -51,17 +63,25 @@ struct hc_cells {
   int brep_enabled = 0, brep_timescale = 1; double brep_const = 0, brep_cutoff = 0; uint8_t *d_bflag = nullptr;
   bool rep_on() const { return rep_enabled || brep_enabled; }
   unsigned int *d_keys[2] = {nullptr, nullptr}; int *d_vals[2] = {nullptr, nullptr}; void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0; long sort_cap = 0;
-  int *d_iscratch[2] = {nullptr, nullptr};   // staged slot lists of the envelope exchange (stream ordered, no sync)
+  // staged slot lists (envelope exchange, interpolate_cells, remove): pinned host block -> device block, stream ordered;
+  // the event guards the pinned block against being rewritten while its copy is still in flight
+  int *d_iscratch[2] = {nullptr, nullptr}, *h_iscratch[2] = {nullptr, nullptr}; hipEvent_t iscratch_ev[2] = {nullptr, nullptr};
   // asynchronous cell extents (hcp_cell_extents_begin / _end): device block, pinned host block and event per type
   double *d_ext[8] = {nullptr}, *h_ext[8] = {nullptr}; long ext_cap[8] = {0}, ext_n[8] = {0}; hipEvent_t ext_done[8] = {nullptr}; bool ext_pending[8] = {false};
   // staging of hcp_add_vertex_force (called every iteration by the stretch drivers): pinned host block + device block
   // [n indices | 3n force components], grown on demand; the event guards the pinned block against reuse in flight
   char *h_vf = nullptr, *d_vf = nullptr; size_t vf_cap = 0; hipEvent_t vf_done = nullptr;
   size_t iscratch_cap[2] = {0, 0};
-  long n_deleted = 0;
+  double *d_stat = nullptr, *h_stat = nullptr;   // [STAT_BLOCKS][4] partials of the statistics reductions, device and pinned host
+  double *d_info = nullptr, *h_info = nullptr; size_t info_cap = 0;   // scratch of the information calls (hcp_cell_info, hcp_mechanics_components, statistics)
+  std::vector<long> slab_rejected;   // (type, cell id) pairs hcp_add_cell rejected at a wall on this slab, until hcp_slab_sync_placement
+  long n_deleted = 0;              // cells removed entirely
+  long n_particles_deleted = 0;    // single particles removed (reference mode), including those of cells removed later
 };
 
 namespace hcc {
+
+constexpr double E_SHARE = 4.0;   // slab runs: a cell within this many lattice units of a face is replicated on the neighbour
 
 // ----------------------------------------------------------------------------
 // lattice view for the IBM kernels
@@ -141,7 +161,7 @@ __device__ __forceinline__ void phi2_stencil(const LatView &v, double px, double
   for (int idx = 0; idx < 8; idx++) s.w[idx] *= coeff;
 }
 
-struct VertArrays { double *p[3], *v[3], *f[3], *r[3]; };   // r: repulsion force arrays or null
+struct VertArrays { double *p[3], *v[3], *f[3], *r[3]; unsigned char *dead; int *tag; };   // r: repulsion force arrays or null; dead / tag offset to the type
 
 // ----------------------------------------------------------------------------
 template <typename T>
@@ -163,9 +183,13 @@ inline std::vector<int> flatten(const std::vector<std::array<long, N>> &v) {
 int free_device_arrays(hc_cells *C);
 int sync_to_device(hc_cells *C);   // host staging -> device arrays when the host copy is newer
 int sync_to_host(hc_cells *C);     // device arrays -> host staging before host-side edits
+// make the host's view of the cell set current: reads the deletion counters (one small blocking copy, and only when an
+// advance ran since the last time) and compacts gone cells away.  Every entry point that reports or edits cells calls it.
+int settle(hc_cells *C);
 VertArrays vert_arrays(hc_cells *C, int t);
-// stage a small host int array on the device in a persistent scratch slot (stream ordered, no host sync)
+// stage a small host int array on the device in a persistent scratch slot (through a pinned block; stream ordered)
 int stage_ints(hc_cells *C, int which, int **d, const int *h, int n);
+void host_append_state(hc_cells *C, int type, long cell_id);
 
 }  // namespace hcc
 using namespace hcc;

@@ -14,9 +14,12 @@ namespace {
 // ----------------------------------------------------------------------------
 // advance + boundary tagging
 __global__ __launch_bounds__(256) void advance_kernel(LatView v, long n, double *px, double *py, double *pz, const double *vx,
-                                                      const double *vy, const double *vz, const int *vert_cell, int *tag, int *ntag) {
+                                                      const double *vy, const double *vz, const int *vert_cell, int *tag, unsigned char *dead,
+                                                      int *counters, int whole_cell) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  const int cell = vert_cell[i];
+  if (dead[i] || tag[cell] == 1) return;   // removed particle / cell already gone
   const double x = px[i] + vx[i], y = py[i] + vy[i], z = pz[i] + vz[i];
   px[i] = x; py[i] = y; pz[i] = z;
   // nearest node is a boundary -> tag (core/hemoCellParticleField.cpp:571-583)
@@ -26,8 +29,23 @@ __global__ __launch_bounds__(256) void advance_kernel(LatView v, long n, double 
   if (gy < 0 || gy >= v.ny) { if (v.per_y) gy = pmod(gy, v.ny); else inside = false; }
   if (gz < 0 || gz >= v.nz) { if (v.per_z) gz = pmod(gz, v.nz); else inside = false; }
   if (inside && v.mask[(gx + HALO) * (long)v.plane + gy * v.nz + gz] != 0) {
-    if (atomicExch(&tag[vert_cell[i]], 1) == 0) atomicAdd(ntag, 1);
+    if (whole_cell) {   // HC_DELETE_CELL: the cell is gone at once
+      if (atomicExch(&tag[cell], 1) != 1) atomicAdd(&counters[0], 1);
+    } else {            // HC_DELETE_PARTICLE: removeParticles(1) takes this particle out, the cell is incomplete from now on (:584, :304-321)
+      dead[i] = 1;
+      atomicAdd(&counters[2], 1);
+      if (atomicCAS(&tag[cell], 0, 2) == 0) atomicAdd(&counters[1], 1);
+    }
   }
+}
+
+__global__ void sub_counters_kernel(int *counters, int a, int b, int c) { atomicSub(&counters[0], a); atomicSub(&counters[1], b); atomicSub(&counters[2], c); }
+
+// deleteIncompleteCells (core/hemoCellParticleField.cpp:512-553): every incomplete cell goes
+__global__ void delete_incomplete_kernel(long ncells, int *tag, int *counters) {
+  const long c = (long)blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncells) return;
+  if (tag[c] == 2) { tag[c] = 1; atomicAdd(&counters[0], 1); }
 }
 
 __global__ void add_vertex_force_kernel(int n, const long *idx, const double *f, double *fx, double *fy, double *fz) {
@@ -55,7 +73,8 @@ int free_device_arrays(hc_cells *C) {
     C->pos[d] = C->vel[d] = C->frc[d] = nullptr;
   }
   if (C->d_tag) hipFree(C->d_tag);
-  C->d_tag = nullptr; C->cap = 0; C->tag_cap = 0;
+  if (C->d_vdead) hipFree(C->d_vdead);
+  C->d_tag = nullptr; C->d_vdead = nullptr; C->cap = 0; C->tag_cap = 0;
   for (int t = 0; t < 8; t++) C->capc[t] = 0;
   if (C->d_vert_cell) hipFree(C->d_vert_cell);
   C->d_vert_cell = nullptr;
@@ -94,6 +113,7 @@ int sync_to_device(hc_cells *C) {
     if (C->rep_on()) for (int d = 0; d < 3; d++) { HC_HIP(hipMalloc((void **)&C->rep[d], C->cap * sizeof(double))); HC_HIP(hipMemset(C->rep[d], 0, C->cap * sizeof(double))); }
     C->tag_cap = capcells + 1;
     HC_HIP(hipMalloc((void **)&C->d_tag, C->tag_cap * sizeof(int)));
+    HC_HIP(hipMalloc((void **)&C->d_vdead, (size_t)C->cap));
     for (int t = 0; t < C->ntypes; t++) {
       const long n = C->capc[t] * C->types[t]->host.nv;
       hipLaunchKernelGGL(fill_vert_cell_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), n, C->types[t]->host.nv, (int)C->cell0[t], C->first[t], C->d_vert_cell);
@@ -115,7 +135,22 @@ int sync_to_device(hc_cells *C) {
       }
   }
   HC_HIP(hipMemsetAsync(C->d_tag, 0, C->tag_cap * sizeof(int), hc::stream()));
+  HC_HIP(hipMemsetAsync(C->d_vdead, 0, (size_t)C->cap, hc::stream()));
   HC_HIP(hipStreamSynchronize(hc::stream()));
+  for (int t = 0; t < C->ntypes; t++) {
+    const long nc = C->ncells[t], n = nc * C->types[t]->host.nv;
+    if (nc == 0) continue;
+    // deletion state and force_repulsion travel with the cells (a staging written before they existed has none: all live, zero)
+    if ((long)C->htag[t].size() == nc) HC_HIP(hipMemcpy(C->d_tag + C->cell0[t], C->htag[t].data(), (size_t)nc * sizeof(int), hipMemcpyHostToDevice));
+    if ((long)C->hdead[t].size() == n) HC_HIP(hipMemcpy(C->d_vdead + C->first[t], C->hdead[t].data(), (size_t)n, hipMemcpyHostToDevice));
+    if (C->rep[0] && (long)C->hrep[t].size() == 3 * n) {
+      tmp.resize((size_t)n);
+      for (int d = 0; d < 3; d++) {
+        for (long i = 0; i < n; i++) tmp[(size_t)i] = C->hrep[t][(size_t)(3 * i + d)];
+        HC_HIP(hipMemcpy(C->rep[d] + C->first[t], tmp.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+      }
+    }
+  }
   C->host_dirty = false;
   return HC_OK;
 }
@@ -137,6 +172,19 @@ int sync_to_host(hc_cells *C) {
         for (long i = 0; i < n; i++) (*dstv[w])[(size_t)(3 * i + d)] = tmp[(size_t)i];
       }
     }
+    C->htag[t].assign((size_t)C->ncells[t], 0); C->hdead[t].assign((size_t)n, 0);
+    if (C->ncells[t] && C->d_tag) {
+      HC_HIP(hipMemcpy(C->htag[t].data(), C->d_tag + C->cell0[t], (size_t)C->ncells[t] * sizeof(int), hipMemcpyDeviceToHost));
+      HC_HIP(hipMemcpy(C->hdead[t].data(), C->d_vdead + C->first[t], (size_t)n, hipMemcpyDeviceToHost));
+    }
+    C->hrep[t].clear();
+    if (C->rep[0] && n) {
+      C->hrep[t].resize((size_t)(3 * n));
+      for (int d = 0; d < 3; d++) {
+        HC_HIP(hipMemcpy(tmp.data(), C->rep[d] + C->first[t], (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        for (long i = 0; i < n; i++) C->hrep[t][(size_t)(3 * i + d)] = tmp[(size_t)i];
+      }
+    }
   }
   return HC_OK;
 }
@@ -147,22 +195,43 @@ VertArrays vert_arrays(hc_cells *C, int t) {
     a.p[d] = C->pos[d] + C->first[t]; a.v[d] = C->vel[d] + C->first[t]; a.f[d] = C->frc[d] + C->first[t];
     a.r[d] = C->rep[d] ? C->rep[d] + C->first[t] : nullptr;
   }
+  a.dead = C->d_vdead + C->first[t]; a.tag = C->d_tag + C->cell0[t];
   return a;
 }
-// stage a small host int array on the device in a persistent scratch slot; the copy and every later use are
-// ordered on the library stream, so no host synchronisation is needed
+// stage a small host int array on the device in a persistent scratch slot.  The source is copied into a pinned block
+// first, so the caller's array may be a temporary and the copy really is asynchronous; the copy and every later use are
+// ordered on the stream in use.  The slot's event tells when the pinned block may be rewritten.
 int stage_ints(hc_cells *C, int which, int **d, const int *h, int n) {
+  if (!C->iscratch_ev[which]) HC_HIP(hipEventCreateWithFlags(&C->iscratch_ev[which], hipEventDisableTiming));
+  else HC_HIP(hipEventSynchronize(C->iscratch_ev[which]));   // the previous copy has left the pinned block (normally long ago)
   if ((size_t)n > C->iscratch_cap[which]) {
-    HC_HIP(hipStreamSynchronize(hc::stream()));
+    HC_HIP(hipDeviceSynchronize());   // the old device block may still be in use on either stream
     if (C->d_iscratch[which]) HC_HIP(hipFree(C->d_iscratch[which]));
+    if (C->h_iscratch[which]) HC_HIP(hipHostFree(C->h_iscratch[which]));
+    C->d_iscratch[which] = C->h_iscratch[which] = nullptr;
     C->iscratch_cap[which] = (size_t)n * 2 + 256;
     HC_HIP(hipMalloc((void **)&C->d_iscratch[which], C->iscratch_cap[which] * sizeof(int)));
+    HC_HIP(hipHostMalloc((void **)&C->h_iscratch[which], C->iscratch_cap[which] * sizeof(int), hipHostMallocDefault));
   }
-  if (n > 0) HC_HIP(hipMemcpyAsync(C->d_iscratch[which], h, (size_t)n * sizeof(int), hipMemcpyHostToDevice, hc::stream()));
+  if (n > 0) {
+    std::memcpy(C->h_iscratch[which], h, (size_t)n * sizeof(int));
+    HC_HIP(hipMemcpyAsync(C->d_iscratch[which], C->h_iscratch[which], (size_t)n * sizeof(int), hipMemcpyHostToDevice, hc::stream()));
+    HC_HIP(hipEventRecord(C->iscratch_ev[which], hc::stream()));
+  }
   *d = C->d_iscratch[which];
   return HC_OK;
 }
 
+// id, deletion state and force_repulsion of a cell whose vertices were just appended to the host staging of its type
+void host_append_state(hc_cells *C, int type, long cell_id) {
+  const size_t nv = (size_t)C->types[type]->host.nv, nc = C->hids[type].size();
+  C->htag[type].resize(nc, 0); C->hdead[type].resize(nc * nv, 0);
+  if (C->rep_on()) C->hrep[type].resize(3 * nc * nv, 0.0);
+  C->hids[type].push_back(cell_id);
+  C->htag[type].push_back(0); C->hdead[type].resize((nc + 1) * nv, 0);
+  if (C->rep_on()) C->hrep[type].resize(3 * (nc + 1) * nv, 0.0);
+  C->host_dirty = true;
+}
 
 }  // namespace hcc
 
@@ -228,15 +297,28 @@ int hcp_celltype_tables(const hc_celltype *T, double *vertices, long *triangles,
   return HC_OK;
 }
 
+int hcp_celltype_tables2(const hc_celltype *T, long *edge_bending_triangles, long *edge_bending_outer_points, long *inner_edges,
+                         double *inner_edge_length_eq, int *vertex_n_vertexes) {
+  HC_REQUIRE(T, "hcp_celltype_tables2: null cell type");
+  const CellTables &H = T->host;
+  if (edge_bending_triangles) for (int i = 0; i < H.ne; i++) for (int d = 0; d < 2; d++) edge_bending_triangles[2 * i + d] = H.edge_bending_triangles[i][d];
+  if (edge_bending_outer_points) for (int i = 0; i < H.ne; i++) for (int d = 0; d < 2; d++) edge_bending_outer_points[2 * i + d] = H.edge_bending_outer[i][d];
+  if (inner_edges) for (int i = 0; i < H.nie; i++) for (int d = 0; d < 2; d++) inner_edges[2 * i + d] = H.inner_edges[i][d];
+  if (inner_edge_length_eq) std::copy(H.inner_edge_length_eq.begin(), H.inner_edge_length_eq.end(), inner_edge_length_eq);
+  if (vertex_n_vertexes) std::copy(H.vertex_n_vertexes.begin(), H.vertex_n_vertexes.end(), vertex_n_vertexes);
+  return HC_OK;
+}
+
 int hcp_create(hc_cells **out, hc_lattice *L, const hc_params *P) {
   HC_REQUIRE(out && L && P, "hcp_create: null pointer");
   hc_cells *C = new hc_cells();
   C->L = L; C->P = *P;
   L->ibm = 1;
-  HC_HIP(hipHostMalloc((void **)&C->h_ntag, sizeof(int), hipHostMallocDefault));
-  *C->h_ntag = 0;
-  HC_HIP(hipMalloc((void **)&C->d_ntag, sizeof(int)));
-  HC_HIP(hipMemset(C->d_ntag, 0, sizeof(int)));
+  HC_HIP(hipHostMalloc((void **)&C->h_ntag, 4 * sizeof(int), hipHostMallocDefault));
+  for (int k = 0; k < 4; k++) C->h_ntag[k] = 0;
+  HC_HIP(hipMalloc((void **)&C->d_ntag, 4 * sizeof(int)));
+  HC_HIP(hipMemset(C->d_ntag, 0, 4 * sizeof(int)));
+  HC_HIP(hipEventCreateWithFlags(&C->ntag_ev, hipEventDisableTiming));
   *out = C;
   return HC_OK;
 }
@@ -247,8 +329,14 @@ int hcp_destroy(hc_cells *C) {
   free_device_arrays(C);
   if (C->h_ntag) hipHostFree(C->h_ntag);
   if (C->d_ntag) hipFree(C->d_ntag);
+  if (C->ntag_ev) hipEventDestroy(C->ntag_ev);
   if (C->d_bflag) hipFree(C->d_bflag);
+  for (int k = 0; k < 2; k++) { if (C->h_iscratch[k]) hipHostFree(C->h_iscratch[k]); if (C->iscratch_ev[k]) hipEventDestroy(C->iscratch_ev[k]); }
   for (int t = 0; t < 8; t++) { if (C->d_ext[t]) hipFree(C->d_ext[t]); if (C->h_ext[t]) hipHostFree(C->h_ext[t]); if (C->ext_done[t]) hipEventDestroy(C->ext_done[t]); }
+  if (C->d_stat) hipFree(C->d_stat);
+  if (C->h_stat) hipHostFree(C->h_stat);
+  if (C->d_info) hipFree(C->d_info);
+  if (C->h_info) hipHostFree(C->h_info);
   if (C->h_vf) hipHostFree(C->h_vf);
   if (C->d_vf) hipFree(C->d_vf);
   if (C->vf_done) hipEventDestroy(C->vf_done);
@@ -270,7 +358,8 @@ int hcp_add_type(hc_cells *C, hc_celltype *T, int material_timescale, int *type_
 int hcp_add_cell(hc_cells *C, int type, long cell_id, const double centre_lu[3], const double angles[3], double min_dist_um, int *placed) {
   HC_REQUIRE(C && centre_lu && angles, "hcp_add_cell: null pointer");
   HC_REQUIRE(type >= 0 && type < C->ntypes, "hcp_add_cell: unknown cell type");
-  int rc = sync_to_host(C); if (rc != HC_OK) return rc;
+  int rc = settle(C); if (rc != HC_OK) return rc;
+  rc = sync_to_host(C); if (rc != HC_OK) return rc;
   const CellTables &T = C->types[type]->host;
   const hc_lattice *L = C->L;
   const int nv = T.nv;
@@ -301,40 +390,64 @@ int hcp_add_cell(hc_cells *C, int type, long cell_id, const double centre_lu[3],
     if (lz < 0 || lz >= L->nz) { if (L->periodic[2]) lz = ((lz % L->nz) + L->nz) % L->nz; else return false; }
     return mask[(size_t)(lx + HALO) * L->xs + (size_t)ly * L->nz + lz] != 0;
   };
+  // slab of a multi-rank run: keep the cell (or its periodic image, shifted by the domain length as
+  // core/hemoCellParticleDataTransfer.cpp:33-65 does) when one of its particles lives here or it reaches within the
+  // envelope of a face; otherwise it is another rank's
+  double cx = centre_lu[0];
+  if (L->n_slabs > 1) {
+    const double x0 = (double)L->x0, x1 = (double)(L->x0 + L->nx);
+    const double shifts[3] = {0.0, -(double)L->nx_global, (double)L->nx_global};
+    bool mine = false;
+    for (int k = 0; k < (L->periodic[0] ? 3 : 1) && !mine; k++) {
+      double lo = 1e300, hi = -1e300; bool own = false;
+      for (int i = 0; i < nv; i++) {
+        const double x = centre_lu[0] + shifts[k] + m[i][0];
+        lo = std::min(lo, x); hi = std::max(hi, x);
+        const double g = std::floor(x + 0.5);
+        own = own || (g >= x0 && g < x1);
+      }
+      if (own || (hi >= x0 - E_SHARE && lo < x1 + E_SHARE)) { mine = true; cx = centre_lu[0] + shifts[k]; }
+    }
+    if (!mine) { if (placed) *placed = 0; return HC_OK; }
+  }
   const int deny = (int)((min_dist_um * 1e-6) / C->P.dx);
   bool ok = true;
   for (int i = 0; i < nv && ok; i++) {
-    const double v[3] = {centre_lu[0] + m[i][0], centre_lu[1] + m[i][1], centre_lu[2] + m[i][2]};
+    const double v[3] = {cx + m[i][0], centre_lu[1] + m[i][1], centre_lu[2] + m[i][2]};
     const long n[3] = {(long)std::floor(v[0] + 0.5), (long)std::floor(v[1] + 0.5), (long)std::floor(v[2] + 0.5)};  // int(vertex+0.5), :135
     if (is_boundary(n[0], n[1], n[2])) { ok = false; break; }
     for (int a = -deny; a <= deny && ok; a++) for (int b = -deny; b <= deny && ok; b++) for (int c = -deny; c <= deny; c++)
       if (is_boundary(n[0] + a, n[1] + b, n[2] + c)) { ok = false; break; }
   }
   if (placed) *placed = ok ? 1 : 0;
-  if (!ok) return HC_OK;
-  for (int i = 0; i < nv; i++) {
-    for (int d = 0; d < 3; d++) { C->hpos[type].push_back(centre_lu[d] + m[i][d]); C->hvel[type].push_back(0.0); C->hfrc[type].push_back(0.0); }
+  if (!ok) {
+    if (L->n_slabs > 1) { C->slab_rejected.push_back(type); C->slab_rejected.push_back(cell_id); }   // the other holders must drop it too
+    return HC_OK;
   }
-  C->hids[type].push_back(cell_id);
-  C->host_dirty = true;
+  for (int i = 0; i < nv; i++) {
+    C->hpos[type].push_back(cx + m[i][0]); C->hpos[type].push_back(centre_lu[1] + m[i][1]); C->hpos[type].push_back(centre_lu[2] + m[i][2]);
+    for (int d = 0; d < 3; d++) { C->hvel[type].push_back(0.0); C->hfrc[type].push_back(0.0); }
+  }
+  host_append_state(C, type, cell_id);
   return HC_OK;
 }
 
 int hcp_add_cell_unchecked(hc_cells *C, int type, long cell_id, const double centre_lu[3], const double angles[3]) {
   HC_REQUIRE(C && centre_lu && angles, "hcp_add_cell_unchecked: null pointer");
   HC_REQUIRE(type >= 0 && type < C->ntypes, "hcp_add_cell_unchecked: unknown cell type");
-  int rc = sync_to_host(C); if (rc != HC_OK) return rc;
+  int rc = settle(C); if (rc != HC_OK) return rc;
+  rc = sync_to_host(C); if (rc != HC_OK) return rc;
   const CellTables &T = C->types[type]->host;
   (void)angles;
   for (int i = 0; i < T.nv; i++)
     for (int d = 0; d < 3; d++) { C->hpos[type].push_back(centre_lu[d] + T.vertices[i][d]); C->hvel[type].push_back(0.0); C->hfrc[type].push_back(0.0); }
-  C->hids[type].push_back(cell_id);
-  C->host_dirty = true;
+  host_append_state(C, type, cell_id);
   return HC_OK;
 }
 
-int hcp_counts(const hc_cells *C, long *n_vertices, long *n_cells, long *n_deleted) {
+int hcp_counts(hc_cells *C, long *n_vertices, long *n_cells, long *n_deleted) {
   HC_REQUIRE(C, "hcp_counts: null pointer");
+  { int rc = settle(C); if (rc != HC_OK) return rc; }
   long nv = 0, nc = 0;
   for (int t = 0; t < C->ntypes; t++) { nc += (long)C->hids[t].size(); nv += (long)C->hids[t].size() * C->types[t]->host.nv; }
   if (n_vertices) *n_vertices = nv;
@@ -343,8 +456,9 @@ int hcp_counts(const hc_cells *C, long *n_vertices, long *n_cells, long *n_delet
   return HC_OK;
 }
 
-int hcp_type_range(const hc_cells *C, int type, long *first_vertex, long *n_cells) {
+int hcp_type_range(hc_cells *C, int type, long *first_vertex, long *n_cells) {
   HC_REQUIRE(C && type >= 0 && type < C->ntypes, "hcp_type_range: bad arguments");
+  { int rc = settle(C); if (rc != HC_OK) return rc; }
   long f = 0;
   for (int t = 0; t < type; t++) f += (long)C->hids[t].size() * C->types[t]->host.nv;
   if (first_vertex) *first_vertex = f;
@@ -354,7 +468,8 @@ int hcp_type_range(const hc_cells *C, int type, long *first_vertex, long *n_cell
 
 int hcp_download(hc_cells *C, int what, double *out) {
   HC_REQUIRE(C && out && what >= 0 && what <= 2, "hcp_download: bad arguments");
-  int rc = sync_to_host(C); if (rc != HC_OK) return rc;
+  int rc = settle(C); if (rc != HC_OK) return rc;
+  rc = sync_to_host(C); if (rc != HC_OK) return rc;
   size_t o = 0;
   for (int t = 0; t < C->ntypes; t++) {
     const std::vector<double> &src = what == 0 ? C->hpos[t] : what == 1 ? C->hvel[t] : C->hfrc[t];
@@ -366,7 +481,8 @@ int hcp_download(hc_cells *C, int what, double *out) {
 
 int hcp_upload(hc_cells *C, int what, const double *in) {
   HC_REQUIRE(C && in && what >= 0 && what <= 2, "hcp_upload: bad arguments");
-  int rc = sync_to_host(C); if (rc != HC_OK) return rc;
+  int rc = settle(C); if (rc != HC_OK) return rc;
+  rc = sync_to_host(C); if (rc != HC_OK) return rc;
   size_t o = 0;
   for (int t = 0; t < C->ntypes; t++) {
     std::vector<double> &dst = what == 0 ? C->hpos[t] : what == 1 ? C->hvel[t] : C->hfrc[t];
@@ -393,22 +509,23 @@ static_assert(offsetof(SvRecord, cellId) == 96 && offsetof(SvRecord, vertexId) =
 
 int hcp_download_records(hc_cells *C, void *records, long n_records) {
   HC_REQUIRE(C && records && n_records >= 0, "hcp_download_records: bad arguments");
-  int rc = sync_to_host(C); if (rc != HC_OK) return rc;
+  int rc = settle(C); if (rc != HC_OK) return rc;
+  rc = sync_to_host(C); if (rc != HC_OK) return rc;
   long total = 0;
-  for (int t = 0; t < C->ntypes; t++) total += (long)C->hids[t].size() * C->types[t]->host.nv;
-  HC_REQUIRE(n_records == total, "hcp_download_records: the buffer must hold exactly one record per vertex (hcp_counts)");
-  std::vector<double> rep((size_t)(3 * total), 0.0);
-  if (C->rep[0] && total) { rc = hcp_download_repulsion(C, rep.data()); if (rc != HC_OK) return rc; }
+  for (int t = 0; t < C->ntypes; t++) { total += (long)C->hids[t].size() * C->types[t]->host.nv; for (unsigned char dd : C->hdead[t]) total -= dd ? 1 : 0; }
+  HC_REQUIRE(n_records == total, "hcp_download_records: the buffer must hold exactly one record per particle (hcp_counts vertices minus hcp_deletion_counts removed-and-still-listed particles)");
   SvRecord *out = static_cast<SvRecord *>(records);
   long o = 0;
   for (int t = 0; t < C->ntypes; t++) {
     const int nv = C->types[t]->host.nv;
+    const bool has_rep = C->hrep[t].size() == C->hpos[t].size();
     for (size_t c = 0; c < C->hids[t].size(); c++)
-      for (int i = 0; i < nv; i++, o++) {
-        SvRecord &r = out[o];
+      for (int i = 0; i < nv; i++) {
+        if (C->hdead[t][c * (size_t)nv + (size_t)i]) continue;   // a particle removeParticles(1) took out (core/hemoCellParticleField.cpp:304-321)
+        SvRecord &r = out[o++];
         std::memset(&r, 0, sizeof(r));
         const size_t k = 3 * (c * (size_t)nv + (size_t)i);
-        for (int d = 0; d < 3; d++) { r.v[d] = C->hvel[t][k + d]; r.position[d] = C->hpos[t][k + d]; r.force[d] = C->hfrc[t][k + d]; r.force_repulsion[d] = rep[(size_t)(3 * o + d)]; }
+        for (int d = 0; d < 3; d++) { r.v[d] = C->hvel[t][k + d]; r.position[d] = C->hpos[t][k + d]; r.force[d] = C->hfrc[t][k + d]; r.force_repulsion[d] = has_rep ? C->hrep[t][k + d] : 0.0; }
         r.cellId = C->hids[t][c]; r.vertexId = (unsigned short)i; r.restime = 0; r.celltype = (unsigned char)t;
       }
   }
@@ -420,7 +537,8 @@ int hcp_download_records(hc_cells *C, void *records, long n_records) {
 // of their first record within their type.
 int hcp_upload_records(hc_cells *C, const void *records, long n_records) {
   HC_REQUIRE(C && (records || n_records == 0) && n_records >= 0, "hcp_upload_records: bad arguments");
-  int rc = sync_to_host(C); if (rc != HC_OK) return rc;
+  int rc = settle(C); if (rc != HC_OK) return rc;
+  rc = sync_to_host(C); if (rc != HC_OK) return rc;
   const SvRecord *in = static_cast<const SvRecord *>(records);
   std::vector<long> ids[8]; std::vector<double> pos[8], vel[8], frc[8], rep[8]; std::vector<int> seen[8];
   std::vector<std::pair<long, long>> index[8];   // (cellId, slot), sorted on demand
@@ -443,26 +561,18 @@ int hcp_upload_records(hc_cells *C, const void *records, long n_records) {
     for (int d = 0; d < 3; d++) { pos[t][3 * v + d] = r.position[d]; vel[t][3 * v + d] = r.v[d]; frc[t][3 * v + d] = r.force[d]; rep[t][3 * v + d] = r.force_repulsion[d]; }
   }
   for (int t = 0; t < C->ntypes; t++) for (int s : seen[t]) HC_REQUIRE(s, "hcp_upload_records: incomplete cell (a vertexId is missing)");
-  for (int t = 0; t < C->ntypes; t++) { C->hids[t].swap(ids[t]); C->hpos[t].swap(pos[t]); C->hvel[t].swap(vel[t]); C->hfrc[t].swap(frc[t]); }
-  C->host_dirty = true;
-  rc = sync_to_device(C); if (rc != HC_OK) return rc;
-  if (C->rep[0]) {   // force_repulsion lives on the device only
-    std::vector<double> tmp;
-    for (int t = 0; t < C->ntypes; t++) {
-      const size_t n = rep[t].size() / 3;
-      if (!n) continue;
-      tmp.resize(n);
-      for (int d = 0; d < 3; d++) {
-        for (size_t i = 0; i < n; i++) tmp[i] = rep[t][3 * i + d];
-        HC_HIP(hipMemcpy(C->rep[d] + C->first[t], tmp.data(), n * sizeof(double), hipMemcpyHostToDevice));
-      }
-    }
+  for (int t = 0; t < C->ntypes; t++) {
+    C->hids[t].swap(ids[t]); C->hpos[t].swap(pos[t]); C->hvel[t].swap(vel[t]); C->hfrc[t].swap(frc[t]);
+    C->htag[t].assign(C->hids[t].size(), 0); C->hdead[t].assign(C->hids[t].size() * (size_t)C->types[t]->host.nv, 0);
+    if (C->rep_on()) C->hrep[t].swap(rep[t]); else C->hrep[t].clear();   // force_repulsion travels through the staging
   }
-  return HC_OK;
+  C->host_dirty = true;
+  return sync_to_device(C);
 }
 
 int hcp_download_cell_ids(hc_cells *C, long *ids) {
   HC_REQUIRE(C && ids, "hcp_download_cell_ids: null pointer");
+  { int rc = settle(C); if (rc != HC_OK) return rc; }
   size_t o = 0;
   for (int t = 0; t < C->ntypes; t++) { std::copy(C->hids[t].begin(), C->hids[t].end(), ids + o); o += C->hids[t].size(); }
   return HC_OK;
@@ -506,30 +616,118 @@ int hcp_add_vertex_force(hc_cells *C, const long *vertex_index, int n, const dou
   return HC_OK;
 }
 
-// remove tagged cells (host round trip; rare)
-static int purge_tagged(hc_cells *C) {
-  HC_HIP(hipMemcpyAsync(C->h_ntag, C->d_ntag, sizeof(int), hipMemcpyDeviceToHost, hc::stream()));
-  HC_HIP(hipStreamSynchronize(hc::stream()));
-  if (*C->h_ntag == 0) return HC_OK;
-  std::vector<int> tags((size_t)C->tag_cap);
-  HC_HIP(hipMemcpy(tags.data(), C->d_tag, (size_t)C->tag_cap * sizeof(int), hipMemcpyDeviceToHost));
+}  // extern "C"
+
+// ---- deletion bookkeeping.  Cells and particles are deleted ON THE DEVICE by the advance kernel (tag / dead flags that
+// every kernel honours), so a step never waits for the host.  The host's view (cell counts, ids, compact storage) is
+// brought up to date lazily: settle() when somebody asks, poll_deletions() from hc_iterate without ever blocking.
+static int compact_gone(hc_cells *C) {
   int rc = sync_to_host(C); if (rc != HC_OK) return rc;
   for (int t = 0; t < C->ntypes; t++) {
-    const long nc = C->ncells[t]; const int nv = C->types[t]->host.nv;
-    std::vector<double> np, nvl, nf; std::vector<long> nid;
-    for (long c = 0; c < nc; c++) {
-      if (tags[(size_t)(C->cell0[t] + c)]) { C->n_deleted++; continue; }
-      np.insert(np.end(), C->hpos[t].begin() + 3 * c * nv, C->hpos[t].begin() + 3 * (c + 1) * nv);
-      nvl.insert(nvl.end(), C->hvel[t].begin() + 3 * c * nv, C->hvel[t].begin() + 3 * (c + 1) * nv);
-      nf.insert(nf.end(), C->hfrc[t].begin() + 3 * c * nv, C->hfrc[t].begin() + 3 * (c + 1) * nv);
-      nid.push_back(C->hids[t][(size_t)c]);
+    const size_t nc = C->hids[t].size(), nv = (size_t)C->types[t]->host.nv;
+    const bool has_rep = C->hrep[t].size() == 3 * nc * nv;
+    size_t w = 0;
+    for (size_t c = 0; c < nc; c++) {
+      if (C->htag[t][c] == 1) { C->n_deleted++; continue; }
+      if (w != c) {
+        std::copy(C->hpos[t].begin() + 3 * c * nv, C->hpos[t].begin() + 3 * (c + 1) * nv, C->hpos[t].begin() + 3 * w * nv);
+        std::copy(C->hvel[t].begin() + 3 * c * nv, C->hvel[t].begin() + 3 * (c + 1) * nv, C->hvel[t].begin() + 3 * w * nv);
+        std::copy(C->hfrc[t].begin() + 3 * c * nv, C->hfrc[t].begin() + 3 * (c + 1) * nv, C->hfrc[t].begin() + 3 * w * nv);
+        if (has_rep) std::copy(C->hrep[t].begin() + 3 * c * nv, C->hrep[t].begin() + 3 * (c + 1) * nv, C->hrep[t].begin() + 3 * w * nv);
+        std::copy(C->hdead[t].begin() + c * nv, C->hdead[t].begin() + (c + 1) * nv, C->hdead[t].begin() + w * nv);
+        C->htag[t][w] = C->htag[t][c]; C->hids[t][w] = C->hids[t][c];
+      }
+      w++;
     }
-    C->hpos[t].swap(np); C->hvel[t].swap(nvl); C->hfrc[t].swap(nf); C->hids[t].swap(nid);
+    C->hpos[t].resize(3 * w * nv); C->hvel[t].resize(3 * w * nv); C->hfrc[t].resize(3 * w * nv);
+    if (has_rep) C->hrep[t].resize(3 * w * nv);
+    C->hdead[t].resize(w * nv); C->htag[t].resize(w); C->hids[t].resize(w);
   }
-  *C->h_ntag = 0;
-  HC_HIP(hipMemset(C->d_ntag, 0, sizeof(int)));
   C->host_dirty = true;
   return sync_to_device(C);
+}
+
+// the counters have landed in the pinned block: account for them, compact when cells are gone
+static int apply_counters(hc_cells *C) {
+  const int gone = C->h_ntag[0];
+  C->n_particles_deleted += C->h_ntag[2];
+  if (C->h_ntag[0] == 0 && C->h_ntag[2] == 0) return HC_OK;
+  // take off what was read, not more: advance kernels enqueued after that read may have counted further deletions already
+  hipLaunchKernelGGL(sub_counters_kernel, dim3(1), dim3(1), 0, hc::stream(), C->d_ntag, C->h_ntag[0], C->h_ntag[1], C->h_ntag[2]);
+  HC_HIP(hipGetLastError());
+  C->h_ntag[0] = C->h_ntag[1] = C->h_ntag[2] = 0;
+  return gone ? compact_gone(C) : HC_OK;
+}
+
+namespace hcc {
+int settle(hc_cells *C) {
+  if (C->host_dirty || !C->d_ntag) return HC_OK;      // the host staging is authoritative: nothing ran on the device since
+  if (!C->maybe_tagged && !C->ntag_pending) return HC_OK;
+  C->maybe_tagged = false; C->ntag_pending = false;
+  HC_HIP(hipMemcpyAsync(C->h_ntag, C->d_ntag, 4 * sizeof(int), hipMemcpyDeviceToHost, hc::stream()));
+  HC_HIP(hipStreamSynchronize(hc::stream()));
+  return apply_counters(C);
+}
+}  // namespace hcc
+
+// hc_iterate: pick up an asynchronous counter read if it has completed, start the next one; never waits
+static int poll_deletions(hc_cells *C, bool start_next) {
+  if (C->host_dirty || !C->d_ntag) return HC_OK;
+  if (C->ntag_pending) {
+    if (hipEventQuery(C->ntag_ev) != hipSuccess) return HC_OK;   // still in flight: look again next time
+    C->ntag_pending = false;
+    int rc = apply_counters(C); if (rc != HC_OK) return rc;
+  }
+  if (start_next && C->maybe_tagged) {
+    HC_HIP(hipMemcpyAsync(C->h_ntag, C->d_ntag, 4 * sizeof(int), hipMemcpyDeviceToHost, hc::stream()));
+    HC_HIP(hipEventRecord(C->ntag_ev, hc::stream()));
+    C->ntag_pending = true; C->maybe_tagged = false;
+  }
+  return HC_OK;
+}
+
+extern "C" {
+
+int hcp_set_deletion_mode(hc_cells *C, int mode) {
+  HC_REQUIRE(C && (mode == HC_DELETE_PARTICLE || mode == HC_DELETE_CELL), "hcp_set_deletion_mode: mode must be HC_DELETE_PARTICLE or HC_DELETE_CELL");
+  C->del_mode = mode;
+  return HC_OK;
+}
+
+int hcp_delete_incomplete_cells(hc_cells *C, long *n_cells_removed) {
+  HC_REQUIRE(C, "hcp_delete_incomplete_cells: null pointer");
+  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  const long before = C->n_deleted;
+  if (C->tag_cap > 0 && C->nverts > 0) {
+    hipLaunchKernelGGL(delete_incomplete_kernel, dim3((unsigned)((C->tag_cap + 255) / 256)), dim3(256), 0, hc::stream(), C->tag_cap, C->d_tag, C->d_ntag);
+    HC_HIP(hipGetLastError());
+    C->maybe_tagged = true;
+  }
+  rc = settle(C); if (rc != HC_OK) return rc;
+  if (n_cells_removed) *n_cells_removed = C->n_deleted - before;
+  return HC_OK;
+}
+
+int hcp_deletion_counts(hc_cells *C, long *cells_removed, long *particles_removed, long *incomplete_cells, long *missing_particles) {
+  HC_REQUIRE(C, "hcp_deletion_counts: null pointer");
+  int rc = settle(C); if (rc != HC_OK) return rc;
+  rc = sync_to_host(C); if (rc != HC_OK) return rc;
+  long inc = 0, miss = 0;
+  for (int t = 0; t < C->ntypes; t++) { for (int g : C->htag[t]) inc += g == 2; for (unsigned char d : C->hdead[t]) miss += d ? 1 : 0; }
+  if (cells_removed) *cells_removed = C->n_deleted;
+  if (particles_removed) *particles_removed = C->n_particles_deleted;
+  if (incomplete_cells) *incomplete_cells = inc;
+  if (missing_particles) *missing_particles = miss;
+  return HC_OK;
+}
+
+int hcp_download_alive(hc_cells *C, unsigned char *alive) {
+  HC_REQUIRE(C && alive, "hcp_download_alive: null pointer");
+  int rc = settle(C); if (rc != HC_OK) return rc;
+  rc = sync_to_host(C); if (rc != HC_OK) return rc;
+  size_t o = 0;
+  for (int t = 0; t < C->ntypes; t++) for (unsigned char d : C->hdead[t]) alive[o++] = d ? 0 : 1;
+  return HC_OK;
 }
 
 int hcp_advance(hc_cells *C, int check_deletions) {
@@ -544,30 +742,36 @@ int hcp_advance(hc_cells *C, int check_deletions) {
       if (n == 0) continue;
       hipLaunchKernelGGL(advance_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), v, n, C->pos[0] + f, C->pos[1] + f,
                          C->pos[2] + f, (const double *)(C->vel[0] + f), (const double *)(C->vel[1] + f), (const double *)(C->vel[2] + f),
-                         (const int *)(C->d_vert_cell + f), C->d_tag, C->d_ntag);
+                         (const int *)(C->d_vert_cell + f), C->d_tag, C->d_vdead + f, C->d_ntag, C->del_mode == HC_DELETE_CELL ? 1 : 0);
       HC_HIP(hipGetLastError());
     }
+    C->maybe_tagged = true;
   }
-  if (check_deletions) return purge_tagged(C);
+  if (check_deletions) return settle(C);   // phase-by-phase callers that want the compact storage at once (blocking)
   return HC_OK;
 }
 
 static int g_overlap = 1;   // hc_iterate: run advance + mechanics + the next spread beside the collide on steps without a particle update
-int hc_set_overlap(int on) { g_overlap = on != 0; return HC_OK; }
+int hc_set_overlap(int on) { g_overlap = on != 0; hcs::set_overlap(on); return HC_OK; }
 
 int hc_iterate(hc_lattice *L, hc_cells *C, long *iter, int n, int particle_timescale, int force_limit, int deletion_check_every) {
   HC_REQUIRE(L && C && iter, "hc_iterate: null pointer");
   HC_REQUIRE(C->L == L, "hc_iterate: cells are bound to a different lattice");
-  HC_REQUIRE(L->n_slabs == 1, "hc_iterate: single-slab stepping only; multi-slab runs are driven phase by phase with halo exchange");
   HC_REQUIRE(particle_timescale >= 1 && deletion_check_every >= 1, "hc_iterate: timescales must be >= 1");
+  if (L->n_slabs > 1) return hcs::iterate_slab(L, C, iter, n, particle_timescale, force_limit);
   // Same phases in the same order as HemoCell::iterate.  Between two velocity updates advance(it), mechanics(it) and
   // spread(it+1) depend only on vertex data, not on collide(it): they run on the side stream beside it (the spread
   // adds into the force buffer of the next step, which the previous collide left clean).  Never across the end of
   // the call: the caller may edit vertex forces between calls (HemoCellStretch does).
+  // Deletions (core/hemoCellParticleField.cpp:566-588) happen on the device inside the advance kernel at EVERY iteration,
+  // whatever deletion_check_every says; that argument is only the cadence at which the host looks (without waiting) whether
+  // gone cells can be compacted away.
   struct ForkGuard { ~ForkGuard() { if (hc::forked()) hc::join(); else hc::route(0); } } guard;   // error paths leave one timeline behind
   const bool may_overlap = g_overlap && !C->rep_enabled && !C->brep_enabled;
   bool spread_done = false;
   int rc;
+  if ((rc = sync_to_device(C)) != HC_OK) return rc;
+  if ((rc = poll_deletions(C, false)) != HC_OK) return rc;
   for (int s = 0; s < n; s++) {
     const long it = *iter;
     if (!spread_done) {
@@ -576,14 +780,14 @@ int hc_iterate(hc_lattice *L, hc_cells *C, long *iter, int n, int particle_times
       if ((rc = hcp_spread(C, force_limit)) != HC_OK) return rc;                // :313
     }
     spread_done = false;
-    const bool particle_step = it % particle_timescale == 0, check = (it % deletion_check_every) == 0;
-    const bool overlap = may_overlap && !particle_step && !check && s + 1 < n;
+    const bool particle_step = it % particle_timescale == 0;
+    const bool overlap = may_overlap && !particle_step && s + 1 < n;
     if (overlap && (rc = hc::fork()) != HC_OK) return rc;
     if ((rc = hcl_collide_stream_part(L, 0)) != HC_OK) return rc;               // :317
     hcl_step_end(L);
     if (particle_step) { if ((rc = hcp_interpolate(C)) != HC_OK) return rc; }   // :327-332
     if (overlap) hc::route(1);
-    if ((rc = hcp_advance(C, check)) != HC_OK) return rc;                       // :342
+    if ((rc = hcp_advance(C, 0)) != HC_OK) return rc;                           // :342
     if ((rc = hcp_mechanics(C, it, 0)) != HC_OK) return rc;                     // :345
     if (overlap) {
       if ((rc = hcp_spread(C, force_limit)) != HC_OK) return rc;                // :313 of iteration it + 1
@@ -591,8 +795,9 @@ int hc_iterate(hc_lattice *L, hc_cells *C, long *iter, int n, int particle_times
       spread_done = true;
     }
     *iter = it + 1;                                                             // :374 (force zeroing is fused into the collide kernel)
+    if (!overlap && (it + 1) % deletion_check_every == 0 && s + 1 < n) { if ((rc = poll_deletions(C, true)) != HC_OK) return rc; }   // on the main timeline only
   }
-  return HC_OK;
+  return poll_deletions(C, true);
 }
 
 }  // extern "C"

@@ -74,7 +74,7 @@ __device__ __forceinline__ void stat_block_store(StatAcc a, double *partial /*[S
   }
 }
 // folds the partials (device pointer) on the host; out = {min, max, sum}
-int stat_finish(const double *d_partial, double out[3], long *n);
+int stat_finish(const double *d_partial, double out[3], long *n, double *h_pinned = nullptr);   // h_pinned: [STAT_BLOCKS][4] pinned landing block, or a stack copy
 
 }  // namespace hc
 
@@ -111,3 +111,11 @@ struct hc_lattice {
   double *scratch;       // download staging
   size_t scratch_doubles;
 };
+
+// slab.hip: HemoCell::iterate / collideAndStream on one x-slab of a multi-GPU run (halo and envelope exchange inside)
+namespace hcs {
+int iterate_slab(hc_lattice *L, hc_cells *C, long *iter, int n, int particle_timescale, int force_limit);
+int collide_stream_slab(hc_lattice *L, int nsteps);
+void lattice_destroyed(hc_lattice *L);
+void set_overlap(int on);
+}

@@ -10,25 +10,29 @@
 namespace {
 
 // ---------------------------------------------------------------------------- multi-slab cell exchange
-// per-cell [min_x, max_x, number of vertices whose nearest node lies in this slab]
-__global__ __launch_bounds__(256) void cell_extent_kernel(int nv, const double *px, double *out, int x0, int nx) {
+// per-cell [min_x, max_x, number of particles whose nearest node lies in this slab, deletion state (0 complete, 1 gone,
+// 2 incomplete)]; removed particles of an incomplete cell do not count
+__global__ __launch_bounds__(256) void cell_extent_kernel(int nv, const double *px, double *out, int x0, int nx, const int *tag, const unsigned char *dead) {
   __shared__ double lo[256], hi[256];
   __shared__ int own[256];
   const int tid = threadIdx.x;
   const long base = (long)blockIdx.x * nv;
+  const int state = tag[blockIdx.x];
   double a = 1e300, b = -1e300; int o = 0;
-  for (int i = tid; i < nv; i += 256) {
-    const double x = px[base + i]; a = fmin(a, x); b = fmax(b, x);
-    const long gx = nearest_node(x) - x0;
-    o += (gx >= 0 && gx < nx) ? 1 : 0;
-  }
+  if (state != 1)
+    for (int i = tid; i < nv; i += 256) {
+      if (state == 2 && dead[base + i]) continue;
+      const double x = px[base + i]; a = fmin(a, x); b = fmax(b, x);
+      const long gx = nearest_node(x) - x0;
+      o += (gx >= 0 && gx < nx) ? 1 : 0;
+    }
   lo[tid] = a; hi[tid] = b; own[tid] = o;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
     if (tid < s) { lo[tid] = fmin(lo[tid], lo[tid + s]); hi[tid] = fmax(hi[tid], hi[tid + s]); own[tid] += own[tid + s]; }
     __syncthreads();
   }
-  if (tid == 0) { out[3 * blockIdx.x] = lo[0]; out[3 * blockIdx.x + 1] = hi[0]; out[3 * blockIdx.x + 2] = (double)own[0]; }
+  if (tid == 0) { double *r = out + 4 * (long)blockIdx.x; r[0] = lo[0]; r[1] = hi[0]; r[2] = (double)own[0]; r[3] = (double)state; }
 }
 
 
@@ -51,7 +55,9 @@ __global__ __launch_bounds__(256) void unpack_cells_kernel(int nv, int rec, cons
                                                            int x0, int nx) {
   const long dst = (long)slots[blockIdx.x] * nv, src = (long)blockIdx.x * nv;
   const bool fresh = is_new[blockIdx.x] != 0;
+  if (fresh && threadIdx.x == 0) a.tag[slots[blockIdx.x]] = 0;   // a new copy is a complete cell, whatever lived in this slot before
   for (int i = threadIdx.x; i < nv; i += 256) {
+    if (fresh) a.dead[dst + i] = 0;
     bool take = fresh;
     if (!take) {
       const long gx = nearest_node(a.p[0][dst + i]) - x0;
@@ -69,21 +75,31 @@ __global__ __launch_bounds__(256) void unpack_cells_kernel(int nv, int rec, cons
 
 __global__ __launch_bounds__(256) void move_cells_kernel(int nv, const int *src_slots, const int *dst_slots, VertArrays a) {
   const long src = (long)src_slots[blockIdx.x] * nv, dst = (long)dst_slots[blockIdx.x] * nv;
-  for (int i = threadIdx.x; i < nv; i += 256)
+  if (threadIdx.x == 0) a.tag[dst_slots[blockIdx.x]] = a.tag[src_slots[blockIdx.x]];
+  for (int i = threadIdx.x; i < nv; i += 256) {
+    a.dead[dst + i] = a.dead[src + i];
     for (int d = 0; d < 3; d++) {
       a.p[d][dst + i] = a.p[d][src + i]; a.v[d][dst + i] = a.v[d][src + i]; a.f[d][dst + i] = a.f[d][src + i];
       if (a.r[d]) a.r[d][dst + i] = a.r[d][src + i];
     }
+  }
+}
+// slots [first, first + n) no longer hold a cell: neutral state for whoever moves in next
+__global__ void clear_state_kernel(int nv, long first, long n, VertArrays a) {
+  const long k = (long)blockIdx.x * 256 + threadIdx.x;
+  if (k < n) a.tag[first + k] = 0;
+  if (k < n * nv) a.dead[first * nv + k] = 0;
 }
 
 // ParticleInfo statistics (helper/particleInfo.cpp:30-95): magnitude of v (what 1) or of force + force_repulsion (what 2)
 // over the vertices this slab owns (findParticles(localDomain))
 __global__ __launch_bounds__(256) void vertex_stats_kernel(long n, int what, int all_owned, int x0, int nx, const double *px, const double *a0,
                                                            const double *a1, const double *a2, const double *r0, const double *r1, const double *r2,
-                                                           double *partial, int accumulate) {
+                                                           double *partial, int accumulate, const int *vert_cell, const int *tag, const unsigned char *dead) {
   StatAcc acc{1e300, -1e300, 0.0, 0};
   if (accumulate) { const double *o = partial + 4 * blockIdx.x; if (threadIdx.x == 0 && o[3] > 0) { acc.mn = o[0]; acc.mx = o[1]; acc.sum = o[2]; acc.n = (long)o[3]; } }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)STAT_BLOCKS * 256) {
+    if (dead[i] || tag[vert_cell[i]] == 1) continue;
     if (!all_owned) { const long gx = nearest_node(px[i]) - x0; if (gx < 0 || gx >= nx) continue; }
     double v0 = a0[i], v1 = a1[i], v2 = a2[i];
     if (what == 2 && r0) { v0 = v0 + r0[i]; v1 = v1 + r1[i]; v2 = v2 + r2[i]; }
@@ -93,15 +109,24 @@ __global__ __launch_bounds__(256) void vertex_stats_kernel(long n, int what, int
   stat_block_store(acc, partial);
 }
 
-__global__ __launch_bounds__(256) void owned_count_kernel(long n, const double *px, int x0, int nx, unsigned long long *count) {
+__global__ __launch_bounds__(256) void owned_count_kernel(long n, const double *px, int x0, int nx, unsigned long long *count, const int *vert_cell,
+                                                          const int *tag, const unsigned char *dead) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   int mine = 0;
-  if (i < n) { const long gx = nearest_node(px[i]) - x0; mine = (gx >= 0 && gx < nx) ? 1 : 0; }
+  if (i < n && !dead[i] && tag[vert_cell[i]] != 1) { const long gx = nearest_node(px[i]) - x0; mine = (gx >= 0 && gx < nx) ? 1 : 0; }
   const unsigned long long b = __ballot(mine);
   if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (unsigned long long)__popcll(b));
 }
 
 }  // namespace
+
+// persistent device / pinned host block of the statistics reductions (no allocation per call)
+static int stat_scratch(hc_cells *C) {
+  if (C->d_stat) return HC_OK;
+  HC_HIP(hipMalloc((void **)&C->d_stat, (size_t)STAT_BLOCKS * 4 * sizeof(double)));
+  HC_HIP(hipHostMalloc((void **)&C->h_stat, (size_t)STAT_BLOCKS * 4 * sizeof(double), hipHostMallocDefault));
+  return HC_OK;
+}
 
 extern "C" {
 
@@ -119,15 +144,16 @@ int hcp_cell_extents_begin(hc_cells *C, int type) {
     if (C->h_ext[type]) HC_HIP(hipHostFree(C->h_ext[type]));
     C->d_ext[type] = C->h_ext[type] = nullptr; C->ext_cap[type] = 0;
     const long cap = nc + nc / 4 + 64;
-    HC_HIP(hipMalloc((void **)&C->d_ext[type], (size_t)(3 * cap) * sizeof(double)));
-    HC_HIP(hipHostMalloc((void **)&C->h_ext[type], (size_t)(3 * cap) * sizeof(double), hipHostMallocDefault));
+    HC_HIP(hipMalloc((void **)&C->d_ext[type], (size_t)(4 * cap) * sizeof(double)));
+    HC_HIP(hipHostMalloc((void **)&C->h_ext[type], (size_t)(4 * cap) * sizeof(double), hipHostMallocDefault));
     C->ext_cap[type] = cap;
   }
   if (!C->ext_done[type]) HC_HIP(hipEventCreateWithFlags(&C->ext_done[type], hipEventDisableTiming));
   hipLaunchKernelGGL(cell_extent_kernel, dim3((unsigned)nc), dim3(256), 0, hc::stream(), C->types[type]->host.nv,
-                     (const double *)(C->pos[0] + C->first[type]), C->d_ext[type], C->L->x0, C->L->nx);
+                     (const double *)(C->pos[0] + C->first[type]), C->d_ext[type], C->L->x0, C->L->nx, (const int *)(C->d_tag + C->cell0[type]),
+                     (const unsigned char *)(C->d_vdead + C->first[type]));
   HC_HIP(hipGetLastError());
-  HC_HIP(hipMemcpyAsync(C->h_ext[type], C->d_ext[type], (size_t)(3 * nc) * sizeof(double), hipMemcpyDeviceToHost, hc::stream()));
+  HC_HIP(hipMemcpyAsync(C->h_ext[type], C->d_ext[type], (size_t)(4 * nc) * sizeof(double), hipMemcpyDeviceToHost, hc::stream()));
   HC_HIP(hipEventRecord(C->ext_done[type], hc::stream()));
   return HC_OK;
 }
@@ -139,13 +165,14 @@ int hcp_cell_extents_end(hc_cells *C, int type, double *minmax) {
   C->ext_pending[type] = false;
   if (C->ext_n[type] == 0) return HC_OK;
   HC_HIP(hipEventSynchronize(C->ext_done[type]));
-  std::memcpy(minmax, C->h_ext[type], (size_t)(3 * C->ext_n[type]) * sizeof(double));
+  for (long c = 0; c < C->ext_n[type]; c++) for (int k = 0; k < 3; k++) minmax[3 * c + k] = C->h_ext[type][4 * c + k];
   return HC_OK;
 }
 
 int hcp_cell_extents(hc_cells *C, int type, double *minmax) {
   HC_REQUIRE(C && minmax && type >= 0 && type < C->ntypes, "hcp_cell_extents: bad arguments");
-  int rc = hcp_cell_extents_begin(C, type); if (rc != HC_OK) return rc;
+  int rc = settle(C); if (rc != HC_OK) return rc;
+  rc = hcp_cell_extents_begin(C, type); if (rc != HC_OK) return rc;
   return hcp_cell_extents_end(C, type, minmax);
 }
 
@@ -225,6 +252,11 @@ int hcp_remove_cells(hc_cells *C, int type, const int *slots, int n) {
     hipLaunchKernelGGL(move_cells_kernel, dim3((unsigned)src.size()), dim3(256), 0, hc::stream(), C->types[type]->host.nv, (const int *)d_src, (const int *)d_dst, vert_arrays(C, type));
     HC_HIP(hipGetLastError());
   }
+  {
+    const int nv = C->types[type]->host.nv;
+    hipLaunchKernelGGL(clear_state_kernel, dim3((unsigned)(((long)n * nv + 255) / 256)), dim3(256), 0, hc::stream(), nv, new_nc, (long)n, vert_arrays(C, type));
+    HC_HIP(hipGetLastError());
+  }
   C->ncells[type] = new_nc;
   C->nverts -= (long)n * C->types[type]->host.nv;
   return HC_OK;
@@ -233,20 +265,19 @@ int hcp_remove_cells(hc_cells *C, int type, const int *slots, int n) {
 int hcp_owned_vertices(hc_cells *C, long *n_owned) {
   HC_REQUIRE(C && n_owned, "hcp_owned_vertices: null pointer");
   int rc = sync_to_device(C); if (rc != HC_OK) return rc;
-  unsigned long long *d = nullptr, h = 0;
-  HC_HIP(hipMalloc((void **)&d, sizeof(unsigned long long)));
+  rc = stat_scratch(C); if (rc != HC_OK) return rc;
+  unsigned long long *d = reinterpret_cast<unsigned long long *>(C->d_stat);
   HC_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), hc::stream()));
   for (int t = 0; t < C->ntypes; t++) {
-    const long n = C->ncells[t] * C->types[t]->host.nv;
+    const long n = C->ncells[t] * C->types[t]->host.nv, f = C->first[t];
     if (n == 0) continue;
-    hipLaunchKernelGGL(owned_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), n, (const double *)(C->pos[0] + C->first[t]), C->L->x0, C->L->nx, d);
+    hipLaunchKernelGGL(owned_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), n, (const double *)(C->pos[0] + f), C->L->x0, C->L->nx, d,
+                       (const int *)(C->d_vert_cell + f), (const int *)C->d_tag, (const unsigned char *)(C->d_vdead + f));
   }
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, hc::stream());
-  if (e == hipSuccess) e = hipStreamSynchronize(hc::stream());
-  hipFree(d);
-  if (e != hipSuccess) return hc::hip_fail(e, "hcp_owned_vertices", __FILE__, __LINE__);
-  *n_owned = (long)h;
+  HC_HIP(hipGetLastError());
+  HC_HIP(hipMemcpyAsync(C->h_stat, d, sizeof(unsigned long long), hipMemcpyDeviceToHost, hc::stream()));
+  HC_HIP(hipStreamSynchronize(hc::stream()));
+  *n_owned = (long)*reinterpret_cast<unsigned long long *>(C->h_stat);
   return HC_OK;
 }
 
@@ -255,8 +286,8 @@ int hcp_owned_vertices(hc_cells *C, long *n_owned) {
 int hcp_vertex_stats(hc_cells *C, int what, double out[3], long *n) {
   HC_REQUIRE(C && out && n && (what == 1 || what == 2), "hcp_vertex_stats: bad arguments (what: 1 velocity, 2 force)");
   int rc = sync_to_device(C); if (rc != HC_OK) return rc;
-  double *d_partial = nullptr;
-  HC_HIP(hipMalloc((void **)&d_partial, (size_t)STAT_BLOCKS * 4 * sizeof(double)));
+  rc = stat_scratch(C); if (rc != HC_OK) return rc;
+  double *d_partial = C->d_stat;
   HC_HIP(hipMemsetAsync(d_partial, 0, (size_t)STAT_BLOCKS * 4 * sizeof(double), hc::stream()));
   const hc_lattice *L = C->L;
   int launched = 0;
@@ -267,14 +298,12 @@ int hcp_vertex_stats(hc_cells *C, int what, double out[3], long *n) {
     hipLaunchKernelGGL(vertex_stats_kernel, dim3(STAT_BLOCKS), dim3(256), 0, hc::stream(), nt, what, L->n_slabs == 1 ? 1 : 0, L->x0, L->nx,
                        (const double *)(C->pos[0] + f), (const double *)(src[0] + f), (const double *)(src[1] + f), (const double *)(src[2] + f),
                        C->rep[0] ? (const double *)(C->rep[0] + f) : nullptr, C->rep[1] ? (const double *)(C->rep[1] + f) : nullptr,
-                       C->rep[2] ? (const double *)(C->rep[2] + f) : nullptr, d_partial, launched);
+                       C->rep[2] ? (const double *)(C->rep[2] + f) : nullptr, d_partial, launched, (const int *)(C->d_vert_cell + f), (const int *)C->d_tag,
+                       (const unsigned char *)(C->d_vdead + f));
     launched = 1;
   }
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) rc = hc::stat_finish(d_partial, out, n);
-  hipFree(d_partial);
-  if (e != hipSuccess) return hc::hip_fail(e, "hcp_vertex_stats", __FILE__, __LINE__);
-  return rc;
+  HC_HIP(hipGetLastError());
+  return hc::stat_finish(d_partial, out, n, C->h_stat);
 }
 
 

@@ -12,9 +12,10 @@ namespace {
 // spread
 __global__ __launch_bounds__(256) void ibm_spread_kernel(LatView v, long n, const double *px, const double *py, const double *pz,
                                                          double *fx, double *fy, double *fz, const double *rx, const double *ry, const double *rz,
-                                                         double *F, int limit_on, double f_limit) {
+                                                         double *F, int limit_on, double f_limit, const int *vert_cell, const int *tag, const unsigned char *dead) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  if (dead[i] || tag[vert_cell[i]] == 1) return;   // removed particle / cell gone
   double f0 = fx[i], f1 = fy[i], f2 = fz[i];
   if (limit_on) {  // FORCE_LIMIT cap, core/hemoCellParticleField.cpp:848-852 (mutates sv.force)
     const double mag = sqrt((f0 * f0 + f1 * f1) + f2 * f2);
@@ -77,9 +78,11 @@ __device__ __forceinline__ void node_velocity(const LatView &v, const PopView &p
 }
 
 __global__ __launch_bounds__(256) void ibm_interpolate_kernel(LatView v, PopView pv, long n, const double *px, const double *py,
-                                                              const double *pz, double *vx, double *vy, double *vz) {
+                                                              const double *pz, double *vx, double *vy, double *vz, const int *vert_cell, const int *tag,
+                                                              const unsigned char *dead) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  if (dead[i] || tag[vert_cell[i]] == 1) return;
   Stencil s;
   phi2_stencil(v, px[i], py[i], pz[i], s);
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
@@ -226,15 +229,17 @@ __device__ __forceinline__ void tile_stencil(const Tile &t, const unsigned char 
 
 // shared prologue of the two cell kernels: positions -> registers, tile, mask tile, stencils.
 // returns false (uniformly) when the cell does not fit the tile and the caller must take the fallback path
+// dead: removed particles of an INCOMPLETE cell (null for a complete one); they take no part in anything
 __device__ __forceinline__ bool cell_prologue(const LatView &v, int nv, long base, const double *px, const double *py, const double *pz,
-                                              int *s_red, unsigned char *mt, Tile &t, VStencil vs[NVPT]) {
+                                              const unsigned char *dead, int *s_red, unsigned char *mt, Tile &t, VStencil vs[NVPT]) {
   const int tid = threadIdx.x, nth = blockDim.x;
-  double p[NVPT][3]; int b[NVPT][3];
+  double p[NVPT][3]; int b[NVPT][3]; bool live[NVPT];
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
 #pragma unroll
   for (int j = 0; j < NVPT; j++) {
     const int i = tid + j * nth;
-    if (i < nv) {
+    live[j] = i < nv && !(dead && dead[base + i]);
+    if (live[j]) {
       p[j][0] = px[base + i]; p[j][1] = py[base + i]; p[j][2] = pz[base + i];
       stencil_base(v, p[j][0], p[j][1], p[j][2], b[j]);
 #pragma unroll
@@ -248,20 +253,24 @@ __device__ __forceinline__ bool cell_prologue(const LatView &v, int nv, long bas
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < NVPT; j++) {
-    vs[j].adm = 0;
-    if (tid + j * nth < nv) tile_stencil(t, mt, p[j][0], p[j][1], p[j][2], b[j], vs[j]);
+    vs[j].adm = 0; vs[j].base = 0;
+    if (live[j]) tile_stencil(t, mt, p[j][0], p[j][1], p[j][2], b[j], vs[j]);
   }
   return true;
 }
 
 __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv, const double *px, const double *py, const double *pz,
                                                               double *fx, double *fy, double *fz, const double *rx, const double *ry, const double *rz,
-                                                              double *F, int limit_on, double f_limit, int xcd_ranges) {
+                                                              double *F, int limit_on, double f_limit, int xcd_ranges, const int *tag, const unsigned char *vdead) {
   __shared__ double tile[TILE_CAP];
   __shared__ unsigned char mt[TILE_CAP];
   __shared__ int s_red[6 * MAXW];
   const int tid = threadIdx.x, nth = blockDim.x;
-  const long base = (long)(xcd_ranges ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * nv;
+  const int cell = xcd_ranges ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int state = tag[cell];
+  if (state == 1) return;                                        // the cell is gone
+  const unsigned char *dead = state == 2 ? vdead : nullptr;      // incomplete: skip its removed particles
+  const long base = (long)cell * nv;
   // FORCE_LIMIT cap, core/hemoCellParticleField.cpp:848-852 (mutates sv.force)
   if (limit_on) {
     for (int i = tid; i < nv; i += nth) {
@@ -271,9 +280,10 @@ __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv,
     }
   }
   Tile t; VStencil vs[NVPT];
-  if (!cell_prologue(v, nv, base, px, py, pz, s_red, mt, t, vs)) {
+  if (!cell_prologue(v, nv, base, px, py, pz, dead, s_red, mt, t, vs)) {
     // cell larger than the tile (or mesh larger than the register budget): direct global atomics
     for (int i = tid; i < nv; i += nth) {
+      if (dead && dead[base + i]) continue;
       Stencil s;
       phi2_stencil(v, px[base + i], py[base + i], pz[base + i], s);
       const double f0 = (rx ? rx[base + i] : 0.0) + fx[base + i], f1 = (ry ? ry[base + i] : 0.0) + fy[base + i], f2 = (rz ? rz[base + i] : 0.0) + fz[base + i];
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv,
 #pragma unroll
     for (int j = 0; j < NVPT; j++) {
       const int i = tid + j * nth;
-      if (i >= nv) continue;
+      if (i >= nv || !vs[j].adm) continue;
       const double f = (rc ? rc[base + i] : 0.0) + fc[base + i];   // force_repulsion + force, :857-859
 #pragma unroll
       for (int k = 0; k < 8; k++)
@@ -314,7 +324,8 @@ __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv,
 }
 
 __global__ __launch_bounds__(256) void ibm_interpolate_cell_kernel(LatView v, PopView pv, int nv, const double *px, const double *py,
-                                                                   const double *pz, double *vx, double *vy, double *vz, const int *slots, int xcd_ranges) {
+                                                                   const double *pz, double *vx, double *vy, double *vz, const int *slots, int xcd_ranges,
+                                                                   const int *tag, const unsigned char *vdead) {
   // 54 KB in all, so that three workgroups share a CU: 16-bit slots, and the node list reuses the mask tile
   // (the mask is only read while the stencils are formed)
   constexpr unsigned short FREE = 0xFFFF, MARK = 0xFFFE;
@@ -324,9 +335,13 @@ __global__ __launch_bounds__(256) void ibm_interpolate_cell_kernel(LatView v, Po
   __shared__ double ux[NODE_CAP], uy[NODE_CAP], uz[NODE_CAP];
   __shared__ int s_red[6 * MAXW], s_count;
   const int tid = threadIdx.x, nth = blockDim.x;
-  const long base = (long)(slots ? slots[blockIdx.x] : (xcd_ranges ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x)) * nv;   // slots: only the listed cells of the type
+  const int cell = slots ? slots[blockIdx.x] : (xcd_ranges ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x);   // slots: only the listed cells of the type
+  const int state = tag[cell];
+  if (state == 1) return;
+  const unsigned char *dead = state == 2 ? vdead : nullptr;
+  const long base = (long)cell * nv;
   Tile t; VStencil vs[NVPT];
-  bool tiled = cell_prologue(v, nv, base, px, py, pz, s_red, mt, t, vs);
+  bool tiled = cell_prologue(v, nv, base, px, py, pz, dead, s_red, mt, t, vs);
   const int sy = t.e[2], sx = t.e[1] * t.e[2];
   if (tiled) {
     for (int i = tid; i < t.vol; i += nth) slot[i] = FREE;
@@ -378,6 +393,7 @@ __global__ __launch_bounds__(256) void ibm_interpolate_cell_kernel(LatView v, Po
     return;
   }
   for (int i = tid; i < nv; i += nth) {   // fallback: per-vertex gathers
+    if (dead && dead[base + i]) continue;
     Stencil s;
     phi2_stencil(v, px[base + i], py[base + i], pz[base + i], s);
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
@@ -413,11 +429,13 @@ int hcp_spread(hc_cells *C, int force_limit) {
     if (g_ibm_per_vertex)
       hipLaunchKernelGGL(ibm_spread_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), v, n,
                          (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
-                         C->frc[0] + f, C->frc[1] + f, C->frc[2] + f, rp[0], rp[1], rp[2], C->L->force[C->L->fcur], force_limit, C->P.f_limit);
+                         C->frc[0] + f, C->frc[1] + f, C->frc[2] + f, rp[0], rp[1], rp[2], C->L->force[C->L->fcur], force_limit, C->P.f_limit,
+                         (const int *)(C->d_vert_cell + f), (const int *)C->d_tag, (const unsigned char *)(C->d_vdead + f));
     else
       hipLaunchKernelGGL(ibm_spread_cell_kernel, dim3((unsigned)C->ncells[t]), dim3(nv > 128 ? 256 : 128), 0, hc::stream(), v, nv,
                          (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
-                         C->frc[0] + f, C->frc[1] + f, C->frc[2] + f, rp[0], rp[1], rp[2], C->L->force[C->L->fcur], force_limit, C->P.f_limit, 1);
+                         C->frc[0] + f, C->frc[1] + f, C->frc[2] + f, rp[0], rp[1], rp[2], C->L->force[C->L->fcur], force_limit, C->P.f_limit, 1,
+                         (const int *)(C->d_tag + C->cell0[t]), (const unsigned char *)(C->d_vdead + f));
     HC_HIP(hipGetLastError());
   }
   return HC_OK;
@@ -439,11 +457,13 @@ int hcp_interpolate(hc_cells *C) {
     if (g_ibm_per_vertex)
       hipLaunchKernelGGL(ibm_interpolate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), v, pv, n,
                          (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
-                         C->vel[0] + f, C->vel[1] + f, C->vel[2] + f);
+                         C->vel[0] + f, C->vel[1] + f, C->vel[2] + f, (const int *)(C->d_vert_cell + f), (const int *)C->d_tag,
+                         (const unsigned char *)(C->d_vdead + f));
     else
       hipLaunchKernelGGL(ibm_interpolate_cell_kernel, dim3((unsigned)C->ncells[t]), dim3(nv > 128 ? 256 : 128), 0, hc::stream(), v, pv, nv,
                          (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
-                         C->vel[0] + f, C->vel[1] + f, C->vel[2] + f, (const int *)nullptr, 1);
+                         C->vel[0] + f, C->vel[1] + f, C->vel[2] + f, (const int *)nullptr, 1, (const int *)(C->d_tag + C->cell0[t]),
+                         (const unsigned char *)(C->d_vdead + f));
     HC_HIP(hipGetLastError());
   }
   return HC_OK;
@@ -465,7 +485,8 @@ int hcp_interpolate_cells(hc_cells *C, int type, const int *slots, int n) {
   const int nv = C->types[type]->host.nv;
   hipLaunchKernelGGL(ibm_interpolate_cell_kernel, dim3((unsigned)n), dim3(nv > 128 ? 256 : 128), 0, hc::stream(), v, pv, nv,
                      (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
-                     C->vel[0] + f, C->vel[1] + f, C->vel[2] + f, (const int *)d_slots, 0);
+                     C->vel[0] + f, C->vel[1] + f, C->vel[2] + f, (const int *)d_slots, 0, (const int *)(C->d_tag + C->cell0[type]),
+                     (const unsigned char *)(C->d_vdead + f));
   HC_HIP(hipGetLastError());
   return HC_OK;
 }

@@ -511,6 +511,7 @@ int hcl_create(hc_lattice **out, int nx, int ny, int nz, const int periodic[3], 
 
 int hcl_destroy(hc_lattice *L) {
   if (!L) return HC_OK;
+  hcs::lattice_destroyed(L);
   hipStreamSynchronize(hc::stream());
   for (int k = 0; k < 2; k++) if (L->f[k]) hipFree(L->f[k]);
   for (int k = 0; k < 3; k++) { if (L->force[k]) hipFree(L->force[k]); if (L->fdirty[k]) hipFree(L->fdirty[k]); }
@@ -526,6 +527,18 @@ int hcl_destroy(hc_lattice *L) {
 int hcl_dims(const hc_lattice *L, int dims[3]) {
   HC_REQUIRE(L && dims, "hcl_dims: null pointer");
   dims[0] = L->nx; dims[1] = L->ny; dims[2] = L->nz;
+  return HC_OK;
+}
+
+int hcl_node_counts(const hc_lattice *L, long counts[3]) {
+  HC_REQUIRE(L && counts, "hcl_node_counts: null pointer");
+  long fluid = 0, active = 0;
+  for (int x = 0; x < L->nx; x++)
+    for (size_t p = 0; p < L->plane; p++) {
+      const uint8_t m = L->hmask[(size_t)(x + HALO) * L->xs + p];
+      fluid += m == 0; active += m != 2;
+    }
+  counts[0] = (long)L->nx * (long)L->plane; counts[1] = fluid; counts[2] = active;
   return HC_OK;
 }
 
@@ -633,7 +646,7 @@ int hcl_step_end(hc_lattice *L) {
 
 int hcl_collide_stream(hc_lattice *L, int nsteps) {
   HC_REQUIRE(L, "hcl_collide_stream: null lattice");
-  HC_REQUIRE(L->n_slabs == 1, "hcl_collide_stream: multi-slab lattices are stepped with hcl_collide_stream_part + halo exchange");
+  if (L->n_slabs > 1) return hcs::collide_stream_slab(L, nsteps);   // faces exchanged inside, beside the interior collide
   for (int s = 0; s < nsteps; s++) {
     int rc = hcl_collide_stream_part(L, 0);
     if (rc != HC_OK) return rc;
@@ -644,6 +657,7 @@ int hcl_collide_stream(hc_lattice *L, int nsteps) {
 
 int hcl_download_populations(hc_lattice *L, double *f_aos) {
   HC_REQUIRE(L && f_aos, "hcl_download_populations: null pointer");
+  if (L->n_slabs > 1) { const int rc = hcl_slab_refresh_halos(L, 2); if (rc != HC_OK) return rc; }   // the post-stream view pulls from the halo planes
   const size_t nd = (size_t)L->nx * L->plane * HC_Q;
   int rc = ensure_scratch(L, nd); if (rc != HC_OK) return rc;
   LatArgs a = make_args(L);
@@ -669,6 +683,7 @@ int hcl_upload_populations(hc_lattice *L, const double *f_aos) {
 
 int hcl_download_rho_u(hc_lattice *L, double *rho, double *u) {
   HC_REQUIRE(L && rho && u, "hcl_download_rho_u: null pointer");
+  if (L->n_slabs > 1) { const int rc = hcl_slab_refresh_halos(L, 2); if (rc != HC_OK) return rc; }
   const size_t n = (size_t)L->nx * L->plane;
   int rc = ensure_scratch(L, n * 4); if (rc != HC_OK) return rc;
   LatArgs a = make_args(L);
@@ -700,6 +715,7 @@ int hcl_zero_ibm_force(hc_lattice *L) {
 
 int hcl_fluid_stats(hc_lattice *L, int what, double out[3], long *n_nodes) {
   HC_REQUIRE(L && out && n_nodes && what >= 0 && what <= 2, "hcl_fluid_stats: bad arguments");
+  if (L->n_slabs > 1 && what == 0) { const int rc0 = hcl_slab_refresh_halos(L, 1); if (rc0 != HC_OK) return rc0; }   // velocities on the face planes pull from the halos
   int rc = ensure_scratch(L, (size_t)STAT_BLOCKS * 4); if (rc != HC_OK) return rc;
   LatArgs a = make_args(L);
   hipLaunchKernelGGL(fluid_stats_kernel, dim3(STAT_BLOCKS), dim3(256), 0, hc::stream(), a, what, L->scratch);

@@ -28,6 +28,7 @@ struct MechArgs {
   double *fx, *fy, *fz;
   double *comp;        // optional [6][ncells*nv][3]
   long ncv;            // ncells*nv (stride of comp)
+  const int *tag;      // per cell of this type: 0 complete, 1 gone, 2 incomplete
 };
 
 #define MaxCellVolumetricChange 0.01   // config/constant_defaults.h:157-173
@@ -42,18 +43,49 @@ constexpr int MD = CellTables::MAXD;
 __device__ __forceinline__ double norm3(double a, double b, double c) { double r = 0.0; r += a * a; r += b * b; r += c * c; return sqrt(r); }
 __device__ __forceinline__ double dot3(double a0, double a1, double a2, double b0, double b1, double b2) { double r = 0.0; r += a0 * b0; r += a1 * b1; r += a2 * b2; return r; }
 
-// one workgroup = one cell.  LDS: positions, per-triangle {volume term, area, unit normal, area-force
-// magnitude}, per-vertex bending vector (RBC) or per-edge {link, visc, bending} vectors (PLT).
+// area, unit normal and area-force magnitude of triangle t from the LDS copy of the positions (helper/array.h:270-285,
+// rbcHighOrderModel.cpp:70-79).  The RBC kernel evaluates this where it is needed instead of keeping five doubles per
+// triangle in LDS: same operations, same bits, and the workgroup drops from 92 KB to 41 KB of LDS (three per CU).
+struct TriGeom { double area, nx, ny, nz; };
+__device__ __forceinline__ TriGeom tri_geom(const double *xs, const double *ys, const double *zs, int i0, int i1, int i2) {
+  const double v0x = xs[i0], v0y = ys[i0], v0z = zs[i0];
+  const double e1x = xs[i1] - v0x, e1y = ys[i1] - v0y, e1z = zs[i1] - v0z, e2x = xs[i2] - v0x, e2y = ys[i2] - v0y, e2z = zs[i2] - v0z;
+  TriGeom g;
+  g.nx = e1y * e2z - e1z * e2y; g.ny = e1z * e2x - e1x * e2z; g.nz = e1x * e2y - e1y * e2x;
+  const double nn = norm3(g.nx, g.ny, g.nz);
+  if (nn != 0.0) { g.area = 0.5 * nn; g.nx /= nn; g.ny /= nn; g.nz /= nn; } else { g.area = 0.0; g.nx = g.ny = g.nz = 0.0; }
+  return g;
+}
+__device__ __forceinline__ double tri_signed_volume(const double *xs, const double *ys, const double *zs, int i0, int i1, int i2) {
+  const double v0x = xs[i0], v0y = ys[i0], v0z = zs[i0], v1x = xs[i1], v1y = ys[i1], v1z = zs[i1], v2x = xs[i2], v2y = ys[i2], v2z = zs[i2];
+  const double v210 = v2x * v1y * v0z, v120 = v1x * v2y * v0z, v201 = v2x * v0y * v1z;
+  const double v021 = v0x * v2y * v1z, v102 = v1x * v0y * v2z, v012 = v0x * v1y * v2z;
+  return (-v210 + v120 + v201 - v021 - v102 + v012);
+}
+
+// one workgroup = one cell.  LDS: positions and the per-triangle signed-volume terms; RBC: per-vertex bending vector;
+// PLT (small mesh): per-triangle {area, unit normal, area-force magnitude} and per-edge {link, visc, bending} vectors.
 template <int MODEL, bool SEPARATE>
 __global__ __launch_bounds__(256) void mechanics_kernel(MechArgs m) {
   extern __shared__ double lds[];
+  constexpr bool PLT = MODEL != HC_MODEL_RBC_HO;
   const int nv = m.nv, nt = m.nt, ne = m.ne;
   double *xs = lds, *ys = xs + nv, *zs = ys + nv;
-  double *tV = zs + nv, *tA = tV + nt, *tNx = tA + nt, *tNy = tNx + nt, *tNz = tNy + nt, *tAfm = tNz + nt;
-  double *ex = tAfm + nt;  // RBC: B[3][nv]; PLT: edge vectors [9][ne]
+  double *tV = zs + nv;
+  double *tA = tV + nt, *tNx = tA + nt, *tNy = tNx + nt, *tNz = tNy + nt, *tAfm = tNz + nt;   // PLT only
+  double *ex = PLT ? tAfm + nt : tV + nt;  // RBC: B[3][nv]; PLT: edge vectors [9][ne]
   __shared__ double s_volume_force;
   const int tid = threadIdx.x, nth = blockDim.x;
   const long base = (long)blockIdx.x * nv;
+  const int state = m.tag[blockIdx.x];
+  if (state == 1) return;   // the cell is gone
+  if (state == 2) {
+    // incomplete cell: applyConstitutiveModel zeroes the force of every particle of the type it finds, but only complete
+    // cells reach ParticleMechanics (core/hemoCellParticleField.cpp:634-669)
+    if (!SEPARATE) for (int i = tid; i < nv; i += nth) { m.fx[base + i] = 0.0; m.fy[base + i] = 0.0; m.fz[base + i] = 0.0; }
+    else for (int i = tid; i < nv; i += nth) for (int c = 0; c < 6; c++) for (int d = 0; d < 3; d++) m.comp[((long)c * m.ncv + base + i) * 3 + d] = 0.0;
+    return;
+  }
 
   for (int i = tid; i < nv; i += nth) { xs[i] = m.px[base + i]; ys[i] = m.py[base + i]; zs[i] = m.pz[base + i]; }
   __syncthreads();
@@ -61,25 +93,21 @@ __global__ __launch_bounds__(256) void mechanics_kernel(MechArgs m) {
   // ---- per-triangle quantities (rbcHighOrderModel.cpp:56-98 / pltSimpleModel.cpp:57-99)
   for (int t = tid; t < nt; t += nth) {
     const int i0 = m.tri[3 * t], i1 = m.tri[3 * t + 1], i2 = m.tri[3 * t + 2];
-    const double v0x = xs[i0], v0y = ys[i0], v0z = zs[i0], v1x = xs[i1], v1y = ys[i1], v1z = zs[i1], v2x = xs[i2], v2y = ys[i2], v2z = zs[i2];
-    const double v210 = v2x * v1y * v0z, v120 = v1x * v2y * v0z, v201 = v2x * v0y * v1z;
-    const double v021 = v0x * v2y * v1z, v102 = v1x * v0y * v2z, v012 = v0x * v1y * v2z;
-    tV[t] = (-v210 + v120 + v201 - v021 - v102 + v012);
-    const double e1x = v1x - v0x, e1y = v1y - v0y, e1z = v1z - v0z, e2x = v2x - v0x, e2y = v2y - v0y, e2z = v2z - v0z;
-    double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
-    const double nn = norm3(nx, ny, nz);
-    double area;
-    if (nn != 0.0) { area = 0.5 * nn; nx /= nn; ny /= nn; nz /= nn; } else { area = 0.0; nx = ny = nz = 0.0; }
-    tA[t] = area; tNx[t] = nx; tNy[t] = ny; tNz[t] = nz;
-    const double aeq = m.tri_area_eq[t];
-    const double areaRatio = (area - aeq) / aeq;
-    tAfm[t] = m.k_area * (areaRatio + areaRatio / fabs(MaxCellSurfaceAreaChange - areaRatio * areaRatio));
+    tV[t] = tri_signed_volume(xs, ys, zs, i0, i1, i2);
+    if (PLT) {
+      const TriGeom g = tri_geom(xs, ys, zs, i0, i1, i2);
+      tA[t] = g.area; tNx[t] = g.nx; tNy[t] = g.ny; tNz[t] = g.nz;
+      const double aeq = m.tri_area_eq[t];
+      const double areaRatio = (g.area - aeq) / aeq;
+      tAfm[t] = m.k_area * (areaRatio + areaRatio / fabs(MaxCellSurfaceAreaChange - areaRatio * areaRatio));
+    }
   }
   __syncthreads();
-  if (tid == 0) {
+  if (tid == nth - 1) {   // a lane of the last wave, which has the smallest share of the pass below
     // the reference accumulates the signed-volume terms sequentially in triangle order; do the same so
-    // that every copy of a cell (other GPUs, the CPU oracle) gets the same bits
+    // that every copy of a cell (other GPUs, the CPU oracle) gets the same bits.  Runs beside the bending / edge pass.
     double volume = 0.0;
+#pragma unroll 8
     for (int t = 0; t < nt; t++) volume += tV[t];
     volume *= (1.0 / 6.0);
     const double vf = (volume - m.volume_eq) / m.volume_eq;
@@ -156,14 +184,24 @@ __global__ __launch_bounds__(256) void mechanics_kernel(MechArgs m) {
       if (t < 0) break;
       const int i0 = m.tri[3 * t], i1 = m.tri[3 * t + 1], i2 = m.tri[3 * t + 2];
       const double cx = (xs[i0] + xs[i1] + xs[i2]) / 3.0, cy = (ys[i0] + ys[i1] + ys[i2]) / 3.0, cz = (zs[i0] + zs[i1] + zs[i2]) / 3.0;
-      const double afm = tAfm[t];
+      double afm;
+      if (PLT) afm = tAfm[t];
+      else {
+        const TriGeom g = tri_geom(xs, ys, zs, i0, i1, i2);
+        const double aeq = m.tri_area_eq[t];
+        const double areaRatio = (g.area - aeq) / aeq;
+        afm = m.k_area * (areaRatio + areaRatio / fabs(MaxCellSurfaceAreaChange - areaRatio * areaRatio));
+      }
       ACC(1)[0] += afm * (cx - x); ACC(1)[1] += afm * (cy - y); ACC(1)[2] += afm * (cz - z);
     }
     for (int k = 0; k < MD; k++) {  // volume force, triangle order (rbcHighOrderModel.cpp:107-113)
       const int t = m.vtri[MD * i + k];
       if (t < 0) break;
-      const double sc = tA[t] / m.area_mean_eq;
-      ACC(0)[0] += (volume_force * tNx[t]) * sc; ACC(0)[1] += (volume_force * tNy[t]) * sc; ACC(0)[2] += (volume_force * tNz[t]) * sc;
+      TriGeom g;
+      if (PLT) { g.area = tA[t]; g.nx = tNx[t]; g.ny = tNy[t]; g.nz = tNz[t]; }
+      else g = tri_geom(xs, ys, zs, m.tri[3 * t], m.tri[3 * t + 1], m.tri[3 * t + 2]);
+      const double sc = g.area / m.area_mean_eq;
+      ACC(0)[0] += (volume_force * g.nx) * sc; ACC(0)[1] += (volume_force * g.ny) * sc; ACC(0)[2] += (volume_force * g.nz) * sc;
     }
     if (MODEL == HC_MODEL_RBC_HO) {
       const double *Bx = ex, *By = ex + nv, *Bz = ex + 2 * nv;
@@ -298,12 +336,13 @@ static MechArgs mech_args(const hc_cells *C, int t) {
   m.vx = C->vel[0] + f; m.vy = C->vel[1] + f; m.vz = C->vel[2] + f;
   m.fx = C->frc[0] + f; m.fy = C->frc[1] + f; m.fz = C->frc[2] + f;
   m.comp = nullptr; m.ncv = C->ncells[t] * T->host.nv;
+  m.tag = C->d_tag + C->cell0[t];
   return m;
 }
 
 static size_t mech_lds_bytes(const CellTables &T) {
-  const size_t extra = T.model == HC_MODEL_RBC_HO ? 3 * (size_t)T.nv : 9 * (size_t)T.ne;
-  return (3 * (size_t)T.nv + 6 * (size_t)T.nt + extra) * sizeof(double);
+  if (T.model == HC_MODEL_RBC_HO) return (6 * (size_t)T.nv + (size_t)T.nt) * sizeof(double);   // positions, bending vectors, signed-volume terms
+  return (3 * (size_t)T.nv + 6 * (size_t)T.nt + 9 * (size_t)T.ne) * sizeof(double);
 }
 
 static int launch_mechanics(hc_cells *C, int t, double *comp) {
@@ -341,42 +380,54 @@ int hcp_mechanics(hc_cells *C, long iter, int forced) {
   return HC_OK;
 }
 
+// persistent device + pinned host scratch of the information calls (drivers call them at every measurement step):
+// no allocation, one asynchronous copy into pinned memory, one wait
+static int info_scratch(hc_cells *C, size_t doubles) {
+  if (C->info_cap >= doubles) return HC_OK;
+  HC_HIP(hipStreamSynchronize(hc::stream()));
+  if (C->d_info) HC_HIP(hipFree(C->d_info));
+  if (C->h_info) HC_HIP(hipHostFree(C->h_info));
+  C->d_info = C->h_info = nullptr; C->info_cap = 0;
+  const size_t cap = doubles + doubles / 4 + 1024;
+  HC_HIP(hipMalloc((void **)&C->d_info, cap * sizeof(double)));
+  HC_HIP(hipHostMalloc((void **)&C->h_info, cap * sizeof(double), hipHostMallocDefault));
+  C->info_cap = cap;
+  return HC_OK;
+}
+
 int hcp_mechanics_components(hc_cells *C, int type, double *comp) {
   HC_REQUIRE(C && comp && type >= 0 && type < C->ntypes, "hcp_mechanics_components: bad arguments");
-  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  int rc = settle(C); if (rc != HC_OK) return rc;
+  rc = sync_to_device(C); if (rc != HC_OK) return rc;
   const long n = C->ncells[type] * C->types[type]->host.nv;
   if (n == 0) return HC_OK;
-  double *d = nullptr;
-  HC_HIP(hipMalloc((void **)&d, (size_t)(18 * n) * sizeof(double)));
-  rc = launch_mechanics(C, type, d);
-  if (rc == HC_OK) {
-    hipError_t e = hipStreamSynchronize(hc::stream());  // the library stream is non-blocking
-    if (e == hipSuccess) e = hipMemcpy(comp, d, (size_t)(18 * n) * sizeof(double), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) rc = hc::hip_fail(e, "hipMemcpy", __FILE__, __LINE__);
-  }
-  hipFree(d);
-  return rc;
+  rc = info_scratch(C, (size_t)(18 * n)); if (rc != HC_OK) return rc;
+  rc = launch_mechanics(C, type, C->d_info); if (rc != HC_OK) return rc;
+  HC_HIP(hipMemcpyAsync(C->h_info, C->d_info, (size_t)(18 * n) * sizeof(double), hipMemcpyDeviceToHost, hc::stream()));
+  HC_HIP(hipStreamSynchronize(hc::stream()));
+  std::memcpy(comp, C->h_info, (size_t)(18 * n) * sizeof(double));
+  return HC_OK;
 }
 
 int hcp_cell_info(hc_cells *C, int type, double *volume, double *area, double *bbox, double *centroid) {
   HC_REQUIRE(C && volume && area && bbox && centroid && type >= 0 && type < C->ntypes, "hcp_cell_info: bad arguments");
-  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  int rc = settle(C); if (rc != HC_OK) return rc;
+  rc = sync_to_device(C); if (rc != HC_OK) return rc;
   const long nc = C->ncells[type];
   if (nc == 0) return HC_OK;
   const CellTables &T = C->types[type]->host;
-  double *d = nullptr;
-  HC_HIP(hipMalloc((void **)&d, (size_t)(11 * nc) * sizeof(double)));
+  rc = info_scratch(C, (size_t)(11 * nc)); if (rc != HC_OK) return rc;
+  double *d = C->d_info;
   const long f = C->first[type];
   hipLaunchKernelGGL(cell_info_kernel, dim3((unsigned)nc), dim3(256), 0, hc::stream(), T.nv, T.nt, (const int *)C->types[type]->d_tri,
                      (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f), d, d + nc, d + 2 * nc, d + 8 * nc);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(hc::stream());
-  if (e == hipSuccess) e = hipMemcpy(volume, d, nc * sizeof(double), hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(area, d + nc, nc * sizeof(double), hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(bbox, d + 2 * nc, 6 * nc * sizeof(double), hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(centroid, d + 8 * nc, 3 * nc * sizeof(double), hipMemcpyDeviceToHost);
-  hipFree(d);
-  if (e != hipSuccess) return hc::hip_fail(e, "hcp_cell_info", __FILE__, __LINE__);
+  HC_HIP(hipGetLastError());
+  HC_HIP(hipMemcpyAsync(C->h_info, d, (size_t)(11 * nc) * sizeof(double), hipMemcpyDeviceToHost, hc::stream()));
+  HC_HIP(hipStreamSynchronize(hc::stream()));
+  std::memcpy(volume, C->h_info, (size_t)nc * sizeof(double));
+  std::memcpy(area, C->h_info + nc, (size_t)nc * sizeof(double));
+  std::memcpy(bbox, C->h_info + 2 * nc, (size_t)(6 * nc) * sizeof(double));
+  std::memcpy(centroid, C->h_info + 8 * nc, (size_t)(3 * nc) * sizeof(double));
   return HC_OK;
 }
 

@@ -14,11 +14,12 @@ namespace {
 // than r_cutoff repel each other with r_const * (r_cutoff / d) along their separation.  The reference visits a
 // same-bin pair twice (its inner loop runs over ordered pairs there), so those pairs count double.  Gather form:
 // every vertex sums over the 27 bins around its own; the bins come from a radix sort of (bin, vertex).
-__global__ void rep_keys_kernel(LatView v, long n, long first, long packed0, const double *px, const double *py, const double *pz, unsigned int *keys, int *vals) {
+__global__ void rep_keys_kernel(LatView v, long n, long first, long packed0, const double *px, const double *py, const double *pz, unsigned int *keys, int *vals,
+                                const int *vert_cell, const int *tag, const unsigned char *dead) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   long lx = nearest_node(px[i]) - v.x0, ly = nearest_node(py[i]), lz = nearest_node(pz[i]);
-  bool ok = true;
+  bool ok = !dead[i] && tag[vert_cell[i]] != 1;   // removed particles and gone cells are in no bin
   if (v.wrap_x) lx = pmod(lx, v.nx); else ok = ok && (lx >= -HALO && lx < v.nx + HALO);
   if (ly < 0 || ly >= v.ny) { if (v.per_y) ly = pmod(ly, v.ny); else ok = false; }
   if (lz < 0 || lz >= v.nz) { if (v.per_z) lz = pmod(lz, v.nz); else ok = false; }
@@ -78,9 +79,11 @@ __global__ __launch_bounds__(256) void rep_force_kernel(LatView v, long cap, lon
 // around its own bin in ascending (x, y, z) order -- the order in which the reference's x-major list of boundary
 // particles reaches it -- and ADDS to force_repulsion (only applyRepulsionForce ever zeroes it, :703).
 __global__ __launch_bounds__(256) void boundary_rep_kernel(LatView v, long n, const uint8_t *bflag, const double *px, const double *py, const double *pz,
-                                                           double *rx, double *ry, double *rz, double br_const, double br_cutoff) {
+                                                           double *rx, double *ry, double *rz, double br_const, double br_cutoff,
+                                                           const int *vert_cell, const int *tag, const unsigned char *dead) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  if (dead[i] || tag[vert_cell[i]] == 1) return;
   const double x = px[i], y = py[i], z = pz[i];
   const long cx = nearest_node(x), cy = nearest_node(y), cz = nearest_node(z);
   if ((cy < 0 || cy >= v.ny) && !v.per_y) return;   // not in the particle grid (update_pg, :158-161)
@@ -148,7 +151,8 @@ int hcp_repulsion(hc_cells *C) {
     const long nt = C->ncells[t] * C->types[t]->host.nv, f = C->first[t];
     if (nt == 0) continue;
     hipLaunchKernelGGL(rep_keys_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, hc::stream(), v, nt, f, packed0,
-                       (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f), C->d_keys[0], C->d_vals[0]);
+                       (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f), C->d_keys[0], C->d_vals[0],
+                       (const int *)(C->d_vert_cell + f), (const int *)C->d_tag, (const unsigned char *)(C->d_vdead + f));
     HC_HIP(hipGetLastError());
     packed0 += nt;
   }
@@ -216,7 +220,8 @@ int hcp_boundary_repulsion(hc_cells *C) {
     if (n == 0) continue;
     hipLaunchKernelGGL(boundary_rep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), v, n, (const uint8_t *)C->d_bflag,
                        (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
-                       C->rep[0] + f, C->rep[1] + f, C->rep[2] + f, C->brep_const, C->brep_cutoff);
+                       C->rep[0] + f, C->rep[1] + f, C->rep[2] + f, C->brep_const, C->brep_cutoff,
+                       (const int *)(C->d_vert_cell + f), (const int *)C->d_tag, (const unsigned char *)(C->d_vdead + f));
     HC_HIP(hipGetLastError());
   }
   return HC_OK;
@@ -225,7 +230,8 @@ int hcp_boundary_repulsion(hc_cells *C) {
 // force_repulsion of every vertex, [n][3] in download order
 int hcp_download_repulsion(hc_cells *C, double *out) {
   HC_REQUIRE(C && out, "hcp_download_repulsion: null pointer");
-  int rc = sync_to_device(C); if (rc != HC_OK) return rc;
+  int rc = settle(C); if (rc != HC_OK) return rc;
+  rc = sync_to_device(C); if (rc != HC_OK) return rc;
   HC_HIP(hipStreamSynchronize(hc::stream()));
   std::vector<double> tmp;
   size_t o = 0;

@@ -64,9 +64,10 @@ static void prof_collect() {
   }
 }
 
-int stat_finish(const double *d_partial, double out[3], long *n) {
-  double h[STAT_BLOCKS * 4];
-  HC_HIP(hipMemcpyAsync(h, d_partial, sizeof(h), hipMemcpyDeviceToHost, g_stream));
+int stat_finish(const double *d_partial, double out[3], long *n, double *h_pinned) {
+  double h_stack[STAT_BLOCKS * 4];
+  double *h = h_pinned ? h_pinned : h_stack;
+  HC_HIP(hipMemcpyAsync(h, d_partial, sizeof(h_stack), hipMemcpyDeviceToHost, g_stream));
   HC_HIP(hipStreamSynchronize(g_stream));
   double mn = 0, mx = 0, sum = 0; long cnt = 0;
   for (int b = 0; b < STAT_BLOCKS; b++) {
@@ -141,6 +142,36 @@ int hc_side_stream(void **hip_stream) {
   HC_REQUIRE(hip_stream, "hc_side_stream: null pointer");
   HC_REQUIRE(hc::g_side, "hc_side_stream: hc_init() has not been called");
   *hip_stream = (void *)hc::g_side;
+  return HC_OK;
+}
+
+#ifndef HC_KERNEL_TAG
+#define HC_KERNEL_TAG "untagged"
+#endif
+const char *hc_build_tag(void) { return HC_KERNEL_TAG; }
+
+int hc_measure_copy_bandwidth(size_t bytes, int repeats, double *gbytes_per_s) {
+  HC_REQUIRE(bytes > 0 && repeats > 0 && gbytes_per_s, "hc_measure_copy_bandwidth: bad arguments");
+  if (!hc::g_stream) { hc::set_error("hc_measure_copy_bandwidth: hc_init() has not been called"); return HC_ERR_STATE; }
+  void *a = nullptr, *b = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipMalloc(&a, bytes);
+  if (e == hipSuccess) e = hipMalloc(&b, bytes);
+  if (e == hipSuccess) e = hipMemsetAsync(a, 1, bytes, hc::g_stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, hc::g_stream);   // warm
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  if (e == hipSuccess) e = hipEventRecord(e0, hc::g_stream);
+  for (int k = 0; k < repeats && e == hipSuccess; k++) e = hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, hc::g_stream);
+  if (e == hipSuccess) e = hipEventRecord(e1, hc::g_stream);
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  if (a) hipFree(a);
+  if (b) hipFree(b);
+  if (e0) hipEventDestroy(e0);
+  if (e1) hipEventDestroy(e1);
+  if (e != hipSuccess) return hc::hip_fail(e, "hc_measure_copy_bandwidth", __FILE__, __LINE__);
+  *gbytes_per_s = 2.0 * (double)bytes * repeats / ((double)ms * 1e-3) / 1e9;
   return HC_OK;
 }
 

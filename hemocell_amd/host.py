@@ -280,8 +280,8 @@ class Cells:
                          "offsets": [0, 24, 48, 72, 96, 104, 108, 112], "itemsize": 120})
 
     def records(self):
-        """every vertex as the reference's particle record"""
-        rec = np.zeros(self.counts()[0], dtype=self.SV_DTYPE)
+        """every particle as the reference's particle record (removed particles of incomplete cells are not listed)"""
+        rec = np.zeros(self.counts()[0] - self.deletion_counts()[3], dtype=self.SV_DTYPE)
         check(self.lib.hcp_download_records(self.ptr, rec.ctypes.data, len(rec)))
         return rec
 
@@ -332,6 +332,28 @@ class Cells:
 
     def advanceParticles(self, check_deletions=True):
         check(self.lib.hcp_advance(self.ptr, int(check_deletions)))
+
+    # what happens to a particle that reaches a wall: the reference removes that single particle
+    # (core/hemoCellParticleField.cpp:566-588, "particle", default) -- or the whole cell goes at once ("cell")
+    def setDeletionMode(self, mode):
+        check(self.lib.hcp_set_deletion_mode(self.ptr, {"particle": 0, "cell": 1}[mode]))
+
+    def deleteIncompleteCells(self):
+        """HemoCellFields::deleteIncompleteCells (core/hemoCellParticleField.cpp:512-553); returns the cells removed"""
+        n = C.c_long()
+        check(self.lib.hcp_delete_incomplete_cells(self.ptr, C.byref(n)))
+        return n.value
+
+    def deletion_counts(self):
+        """(cells removed entirely, particles removed, incomplete cells listed now, their missing particles)"""
+        a, b, c, d = C.c_long(), C.c_long(), C.c_long(), C.c_long()
+        check(self.lib.hcp_deletion_counts(self.ptr, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, d.value
+
+    def alive(self):
+        out = np.empty(self.counts()[0], dtype=np.uint8)
+        check(self.lib.hcp_download_alive(self.ptr, out.ctypes.data))
+        return out.astype(bool)
 
     def applyConstitutiveModel(self, iter_=0, forced=False):
         check(self.lib.hcp_mechanics(self.ptr, int(iter_), int(forced)))

@@ -39,7 +39,8 @@ typedef struct hc_cells hc_cells;       /* all membrane vertices held by this GP
 
 /* ------------------------------------------------------------------ runtime */
 const char *hc_last_error(void);
-/* selects the HIP device, checks it is gfx950; replaces plb::plbInit (core/hemoCell.cpp:80-86) */
+/* selects the HIP device, checks it is gfx950; replaces plb::plbInit (core/hemoCell.cpp:80-86).  A multi-rank run passes
+ * its LOCAL rank modulo hc_device_count (one process per GPU); hc_comm_init_env does that by itself. */
 int hc_init(int device);
 int hc_device_count(int *count);
 /* run every kernel of this library on an existing hipStream_t (e.g. the host framework's current stream); NULL = library stream */
@@ -59,9 +60,51 @@ int hc_set_overlap(int on);
 int hc_profile_enable(int on);
 int hc_profile_read(const char *kernel, double *total_ms, long *launches); /* "collide_stream" (every launch) = "collide_stream_alone" + "collide_stream_beside" (launches with advance / spread on the side stream next to them), "ibm_spread", "ibm_interpolate", "advance", "mechanics" */
 int hc_profile_reset(void);
+/* identifies the build of the dominant kernel: first 16 hex digits of the SHA-256 of csrc/lattice.hip (a committed PMC
+ * traffic figure is only quoted next to a timing when it was measured on the same kernel) */
+const char *hc_build_tag(void);
+/* device-to-device copy of `bytes` on the library stream, `repeats` times: read + written GB/s of the GPU in hand */
+int hc_measure_copy_bandwidth(size_t bytes, int repeats, double *gbytes_per_s);
 /* A/B switch: 1 = per-vertex IBM kernels with direct global atomics instead of the LDS-tiled per-cell kernels */
 int hc_debug_ibm_per_vertex(int on);
 int hc_debug_force_plane_padding(int on); /* tests / A-B runs: lattices created afterwards get the padded x-plane stride whatever their size (1), never (-1), by size (0, default) */
+
+/* ---------------------------------------------------------------- ranks (one process per GPU of one node)
+ * Replaces what plb::plbInit / MPI give the reference (core/hemoCell.cpp:80-86, the MPI calls of SURVEY.md section 2.3):
+ * a rank, a world size and neighbour exchange.  Two layers:
+ *   control plane  a TCP mesh between the ranks (loopback / MASTER_ADDR): bootstrap, barrier, reductions of a few
+ *                  scalars at output cadence, agreement on the placed cells.  Never on the stepping path.
+ *   data plane     HC_TRANSPORT_RCCL: ncclSend / ncclRecv between x-neighbours, grouped, on the library's side stream
+ *                  (RCCL over xGMI; /opt/rocm/lib/librccl.so.1 is loaded on demand); HC_TRANSPORT_TCP: the same messages
+ *                  staged through pinned host memory and the mesh -- for ranks that SHARE a GPU (RCCL refuses two ranks
+ *                  on one device), i.e. rehearsals and tests on a one-GPU box.
+ * hc_comm_init_env reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (torch.distributed.run's names; also
+ * OMPI_COMM_WORLD_RANK / _SIZE / _LOCAL_RANK and PMI_RANK / PMI_SIZE of an mpirun), HEMOCELL_PORT (default MASTER_PORT + 1017)
+ * and HEMOCELL_TRANSPORT = rccl (default) | tcp, selects the device LOCAL_RANK modulo the device count (hc_init) and
+ * connects.  Without those variables it is a one-rank world and does nothing. */
+#define HC_TRANSPORT_NONE 0
+#define HC_TRANSPORT_RCCL 1
+#define HC_TRANSPORT_TCP 2
+int hc_comm_init_env(void);
+/* explicit form; init_device != 0: also hc_init(local_rank % device count).  transport HC_TRANSPORT_NONE builds the control
+ * plane only (host-side use without a GPU: the CPU tests of the mesh). */
+int hc_comm_init(int rank, int world, int local_rank, const char *master_addr, int port, int transport, int init_device);
+int hc_comm_finalize(void);
+int hc_comm_info(int *rank, int *world, int *transport);
+int hc_comm_barrier(void);
+/* v[n] <- reduction over all ranks, folded in rank order on rank 0 (deterministic); op: 0 sum, 1 min, 2 max */
+int hc_comm_allreduce(double *v, int n, int op);
+int hc_comm_bcast(void *buf, size_t bytes, int root);
+/* all[r * bytes ..] <- rank r's block, on every rank (the reference's HemoCellGatheringFunctional, core/hemoCellFunctional.h:101-112) */
+int hc_comm_allgather(const void *mine, size_t bytes, void *all);
+/* neighbour exchange of HOST buffers over the control plane with the same routing rule as the data plane (my low-face
+ * message is the low neighbour's high-halo message; the ring closes when periodic != 0): what the CPU tests check */
+int hc_comm_exchange_host(int periodic, const void *send_lo, size_t n_lo, const void *send_hi, size_t n_hi,
+                          void *recv_lo, size_t m_lo, void *recv_hi, size_t m_hi);
+/* counters of the slab schedule since the last reset (reset != 0 clears them): out[0..7] = envelope records sent, new
+ * copies created, copies dropped, cells deleted at a wall, iterations, host seconds spent enqueueing them, host seconds
+ * waiting for the id headers, velocity-update steps */
+int hc_slab_stats(hc_lattice *L, double out[8], int reset);
 
 /* ------------------------------------------------------------------ lattice */
 /* MultiBlockLattice3D<T,DESCRIPTOR>(nx,ny,nz, new GuoExternalForceBGKdynamics(omega))
@@ -85,8 +128,12 @@ int hcl_set_body_force(hc_lattice *L, const double F[3]);
  * (helper/hemocellInit.hh:71-86): mask classes 3..6 are moving no-slip walls with velocity u (full-way
  * bounce-back + Ladd momentum term; stand-in for Palabos' regularised boundary, which is not available) */
 int hcl_set_wall_velocity(hc_lattice *L, int wall_class, const double u[3]);
-/* lattice->collideAndStream() (core/hemoCell.cpp:317), n times (fluid-only stepping; n_slabs==1) */
+/* lattice->collideAndStream() (core/hemoCell.cpp:317), n times (fluid-only stepping).  On a slab of a multi-rank run
+ * (n_slabs > 1, hc_comm_init* done) the faces are exchanged inside, interior planes colliding meanwhile. */
 int hcl_collide_stream(hc_lattice *L, int nsteps);
+/* bring the x-halo planes of a slab up to date (width 1 or 2, see hcl_halo_doubles) through the data plane; the
+ * download / statistics entry points do it by themselves */
+int hcl_slab_refresh_halos(hc_lattice *L, int width);
 /* one collide-stream of this slab; halos must be current. part: 0 = all planes, 1 = interior planes
  * (those that do not read halo data), 2 = the two face planes; or 3 = planes 2..nx-3, 4 = the two planes next to each
  * face (what a width-2 halo message is packed from, so that it can travel while part 3 runs).
@@ -119,6 +166,9 @@ int hcl_halo_unpack(hc_lattice *L, int side, int width, const double *dev_buf);
  * hcl_collide_stream_part(L, 4) and hcl_step_end): lets the message leave before the interior planes are done */
 int hcl_halo_pack_next(hc_lattice *L, int side, int width, double *dev_buf);
 int hcl_dims(const hc_lattice *L, int dims[3]);
+/* counts[0] = bulk nodes of this slab, [1] = fluid nodes (GuoExternalForceBGKdynamics), [2] = nodes the collide kernel
+ * loads and stores (everything but solid nodes without a fluid neighbour, which full-way bounce-back leaves inert) */
+int hcl_node_counts(const hc_lattice *L, long counts[3]);
 double hcl_mlups_bytes_per_node(const hc_lattice *L); /* algorithmic bytes per node update of the collide kernel */
 
 /* --------------------------------------------------------------- cell types */
@@ -155,6 +205,10 @@ int hcp_celltype_tables(const hc_celltype *T, double *vertices /*[nv][3]*/, long
                         double *triangle_area_eq, long *vertex_vertexes /*[nv][6]*/, double *patch_dist_eq,
                         double scalars[9] /* volume_eq, area_mean_eq, edge_mean_eq, angle_mean_eq, k_volume, k_area, k_link, k_bend, eta_m */);
 
+/* the remaining CommonCellConstants tables (mechanics/commonCellConstants.h:64-85); any pointer may be NULL */
+int hcp_celltype_tables2(const hc_celltype *T, long *edge_bending_triangles /*[ne][2]*/, long *edge_bending_outer_points /*[ne][2]*/,
+                         long *inner_edges /*[nie][2]*/, double *inner_edge_length_eq /*[nie]*/, int *vertex_n_vertexes /*[nv]*/);
+
 /* ---------------------------------------------------------------- cells */
 /* HemoCellFields / HemoCellParticleField (core/hemoCellFields.h:103-158, core/hemoCellParticleField.h:39-207) */
 int hcp_create(hc_cells **out, hc_lattice *L, const hc_params *P);
@@ -162,14 +216,40 @@ int hcp_destroy(hc_cells *C);
 int hcp_add_type(hc_cells *C, hc_celltype *T, int material_timescale /* setMaterialTimeScaleSeparation */, int *type_index);
 /* loadParticles() (io/readPositionsBloodCells.cpp:290-361) for one cell: centre in lattice units (GLOBAL
  * coordinates), angles in radians, already negated as :228-229 does.  placed=0 when a vertex falls on /
- * within min_dist_um of a boundary node (:139-164) and the cell is dropped. */
+ * within min_dist_um of a boundary node (:139-164) and the cell is dropped.
+ * On a slab (n_slabs > 1) every rank offers every cell: the call keeps it when one of its particles has its nearest node in
+ * this slab or it reaches within the envelope of a face (periodic images are tried shifted by +-nx_global,
+ * core/hemoCellParticleDataTransfer.cpp:33-65), placed=0 otherwise; a rank sees the wall only next to its slab, so
+ * hcp_slab_sync_placement must follow the last cell: it drops on every rank the cells any rank rejected and reports how
+ * many distinct cells of each type the whole domain now holds. */
 int hcp_add_cell(hc_cells *C, int type, long cell_id, const double centre_lu[3], const double angles[3],
                  double min_dist_um, int *placed);
 /* slot for a cell whose state is restored afterwards with hcp_upload (checkpoint resume,
  * core/hemoCellFields.cpp:240-275): undeformed mesh at centre_lu, no wall test */
 int hcp_add_cell_unchecked(hc_cells *C, int type, long cell_id, const double centre_lu[3], const double angles[3]);
-int hcp_counts(const hc_cells *C, long *n_vertices, long *n_cells, long *n_deleted);
-int hcp_type_range(const hc_cells *C, int type, long *first_vertex, long *n_cells);
+/* n_vertices counts the listed vertices (cells x vertices per cell; an incomplete cell keeps its slots), n_deleted the
+ * cells removed entirely so far */
+int hcp_slab_sync_placement(hc_cells *C, long *global_cells_per_type /*[n types]*/);
+int hcp_counts(hc_cells *C, long *n_vertices, long *n_cells, long *n_deleted);
+int hcp_type_range(hc_cells *C, int type, long *first_vertex, long *n_cells);
+/* What happens to a particle whose nearest node is a boundary after advance (core/hemoCellParticleField.cpp:566-588):
+ *   HC_DELETE_PARTICLE (default, the reference): removeParticles(1) takes that particle out (:304-321); its cell is
+ *     incomplete from then on -- no mechanics (:634-652), forces of the remaining particles zeroed at the next material
+ *     step (:660-667), still spread / interpolated / advanced -- until hcp_delete_incomplete_cells removes the rest
+ *     (deleteIncompleteCells, :512-553: the reference calls it at every writeOutput, core/hemoCell.cpp:248-252, and at
+ *     velocity-update steps when verbose.cellsDeletedInfo is set, :361-363);
+ *   HC_DELETE_CELL: the whole cell goes at once.
+ * Either way the decision is taken on the device inside the advance kernel and costs no host round trip; slab runs
+ * (n_slabs > 1) remove an incomplete cell on all its holders at the next velocity update, i.e. behave as the reference
+ * with cellsDeletedInfo. */
+#define HC_DELETE_PARTICLE 0
+#define HC_DELETE_CELL 1
+int hcp_set_deletion_mode(hc_cells *C, int mode);
+int hcp_delete_incomplete_cells(hc_cells *C, long *n_cells_removed);
+/* cells removed entirely / single particles removed so far; incomplete cells and missing particles currently listed */
+int hcp_deletion_counts(hc_cells *C, long *cells_removed, long *particles_removed, long *incomplete_cells, long *missing_particles);
+/* alive[i] = 0 for a removed particle of an incomplete cell, in hcp_download order */
+int hcp_download_alive(hc_cells *C, unsigned char *alive);
 /* serializeValues_t fields as [n][3] arrays in cell-major order; what: 0 position 1 velocity 2 force */
 int hcp_download(hc_cells *C, int what, double *out);
 int hcp_upload(hc_cells *C, int what, const double *in);
@@ -214,9 +294,13 @@ int hcp_mechanics(hc_cells *C, long iter, int forced);
 /* separate_force_vectors output mode (core/hemoCellParticleField.cpp:590-614): comp = [6][n][3]
  * (volume, area, bending, link, visc, inner link) for the vertices of one type */
 int hcp_mechanics_components(hc_cells *C, int type, double *comp);
-/* HemoCell::iterate() (core/hemoCell.cpp:299-376) n times, single slab, followed each time by the driver's
- * body-force re-application (examples/pipeflow/pipeflow.cpp:144-146).  particle_timescale =
- * setParticleVelocityUpdateTimeScaleSeparation. iter is read and advanced. */
+/* HemoCell::iterate() (core/hemoCell.cpp:299-376) n times, followed each time by the driver's body-force
+ * re-application (examples/pipeflow/pipeflow.cpp:144-146).  particle_timescale =
+ * setParticleVelocityUpdateTimeScaleSeparation. iter is read and advanced.  Particles that reach a wall are deleted on
+ * the device at EVERY iteration (hcp_set_deletion_mode); deletion_check_every is only how often the host looks, without
+ * waiting, whether storage can be compacted.  On a slab of a multi-rank run (n_slabs > 1) the same call runs the slab
+ * schedule: faces of the 5 crossing populations every step and the particle envelopes at every velocity update
+ * (syncEnvelopes, core/hemoCellFields.cpp:377-499) travel over the data plane beside the interior collide. */
 int hc_iterate(hc_lattice *L, hc_cells *C, long *iter, int n, int particle_timescale, int force_limit,
                int deletion_check_every);
 /* ---- multi-slab particle envelopes: HemoCellFields::syncEnvelopes (core/hemoCellFields.cpp:377-499) and

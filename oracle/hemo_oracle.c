@@ -788,7 +788,7 @@ orc_sim *orc_sim_create(orc_lattice *L, const orc_params *P) {
 }
 void orc_sim_destroy(orc_sim *S) {
   if (!S) return;
-  free(S->particles); free(S->st_nodes); free(S->st_w); free(S->st_n); free(S);
+  free(S->particles); free(S->st_nodes); free(S->st_w); free(S->st_n); free(S->dead); free(S);
 }
 int orc_sim_add_type(orc_sim *S, orc_celltype *T) { S->types[S->ntypes] = T; S->ncells[S->ntypes] = 0; return S->ntypes++; }
 long orc_sim_type_offset(const orc_sim *S, int type) {
@@ -866,6 +866,9 @@ int orc_sim_add_cell(orc_sim *S, int type, const double centre_lu[3], const doub
       for (int d = 0; d < 3; d++) p->position[d] = centre_lu[d] + m[3 * i + d];
       p->cellId = total_cells; p->vertexId = (unsigned short)i; p->celltype = (unsigned char)type;
     }
+    S->dead = (unsigned char *)realloc(S->dead, (size_t)(S->np + nv));
+    memmove(S->dead + off + nv, S->dead + off, (size_t)(S->np - off));
+    memset(S->dead + off, 0, (size_t)nv);
     S->np += nv; S->ncells[type]++;
     S->st_nodes = (long *)realloc(S->st_nodes, sizeof(long) * 8 * (size_t)S->np);
     S->st_w = (double *)realloc(S->st_w, sizeof(double) * 8 * (size_t)S->np);
@@ -886,6 +889,7 @@ void orc_sim_spread(orc_sim *S) {
   for (long p = 0; p < S->np; p++) {
     orc_particle *pt = S->particles + p;
     long *nodes = S->st_nodes + 8 * p; double *w = S->st_w + 8 * p;
+    if (S->dead[p]) { S->st_n[p] = 0; continue; }   /* removed from the particle list (removeParticles, :304-321) */
     S->st_n[p] = orc_phi2_stencil(L, pt->position, nodes, w);
     if (S->force_limit_enabled) {
       const double mag = v_norm(pt->force);
@@ -908,6 +912,7 @@ void orc_sim_interpolate(orc_sim *S) {
 #pragma omp parallel for num_threads(S->L->nthreads) schedule(static) if (S->L->nthreads > 1)
   for (long p = 0; p < S->np; p++) {
     orc_particle *pt = S->particles + p;
+    if (S->dead[p]) continue;
     double vel[3] = {0.0, 0.0, 0.0};
     for (int j = 0; j < S->st_n[p]; j++) {
       double rho, u[3];
@@ -925,18 +930,19 @@ static void delete_cell(orc_sim *S, int type, long cell) {
   memmove(S->st_nodes + 8 * off, S->st_nodes + 8 * (off + nv), sizeof(long) * 8 * (size_t)(S->np - off - nv));
   memmove(S->st_w + 8 * off, S->st_w + 8 * (off + nv), sizeof(double) * 8 * (size_t)(S->np - off - nv));
   memmove(S->st_n + off, S->st_n + off + nv, sizeof(int) * (size_t)(S->np - off - nv));
+  memmove(S->dead + off, S->dead + off + nv, (size_t)(S->np - off - nv));
   S->np -= nv; S->ncells[type]--; S->cells_deleted++;
 }
 
 /* HemoCellParticle::advance (core/hemoCellParticle.h:188-203, Euler) +
- * HemoCellParticleField::advanceParticles (core/hemoCellParticleField.cpp:566-588).
- * The reference tags the single particle whose nearest node is a boundary and
- * removes it, which leaves an incomplete cell that no longer receives
- * mechanics; here the whole cell is removed at once (documented in DESIGN.md). */
+ * HemoCellParticleField::advanceParticles (core/hemoCellParticleField.cpp:566-588): every particle moves; one whose
+ * nearest node is a boundary gets tag 1 and removeParticles(1) (:584, :304-321) takes it out of the list.  With
+ * deletion_mode 1 the whole cell goes instead. */
 void orc_sim_advance(orc_sim *S) {
 #pragma omp parallel for num_threads(S->L->nthreads) schedule(static) if (S->L->nthreads > 1)
   for (long p = 0; p < S->np; p++) {
     orc_particle *pt = S->particles + p;
+    if (S->dead[p]) continue;
     for (int d = 0; d < 3; d++) pt->position[d] += pt->v[d];
   }
   for (int t = 0; t < S->ntypes; t++) {
@@ -944,16 +950,39 @@ void orc_sim_advance(orc_sim *S) {
     for (long c = 0; c < S->ncells[t]; c++) {
       long off = orc_sim_type_offset(S, t) + c * nv;
       int tagged = 0;
-      for (long i = 0; i < nv && !tagged; i++) {
+      for (long i = 0; i < nv; i++) {
+        if (S->dead[off + i]) continue;
         const double *x = S->particles[off + i].position;
         long nx = (long)floor(x[0] + 0.5), ny = (long)floor(x[1] + 0.5), nz = (long)floor(x[2] + 0.5);
         int inside;
-        if (node_is_boundary_abs(S->L, nx, ny, nz, &inside)) tagged = 1;
+        if (node_is_boundary_abs(S->L, nx, ny, nz, &inside)) {
+          tagged = 1;
+          if (S->deletion_mode == 0) { S->dead[off + i] = 1; S->particles_deleted++; } else break;
+        }
       }
-      if (tagged) { delete_cell(S, t, c); c--; }
+      if (tagged && S->deletion_mode != 0) { delete_cell(S, t, c); c--; }
     }
   }
 }
+
+static int cell_is_complete(const orc_sim *S, long off, long nv) {
+  for (long i = 0; i < nv; i++) if (S->dead[off + i]) return 0;
+  return 1;
+}
+
+/* HemoCellParticleField::deleteIncompleteCells, core/hemoCellParticleField.cpp:512-553 */
+long orc_sim_delete_incomplete_cells(orc_sim *S) {
+  long removed = 0;
+  for (int t = 0; t < S->ntypes; t++) {
+    const long nv = S->types[t]->nv;
+    for (long c = 0; c < S->ncells[t]; c++) {
+      const long off = orc_sim_type_offset(S, t) + c * nv;
+      if (!cell_is_complete(S, off, nv)) { delete_cell(S, t, c); c--; removed++; }
+    }
+  }
+  return removed;
+}
+void orc_sim_get_alive(const orc_sim *S, unsigned char *alive) { for (long p = 0; p < S->np; p++) alive[p] = S->dead[p] ? 0 : 1; }
 
 /* HemoCellParticleField::applyConstitutiveModel, core/hemoCellParticleField.cpp:633-675 */
 void orc_sim_mechanics(orc_sim *S, int forced) {
@@ -970,6 +999,11 @@ void orc_sim_mechanics(orc_sim *S, int forced) {
 #pragma omp for schedule(static)
       for (long c = 0; c < S->ncells[t]; c++) {
         orc_particle *cp = S->particles + off + c * nv;
+        if (!cell_is_complete(S, off + c * nv, nv)) {
+          /* every particle of the type has its force zeroed (:660-667), but only complete cells reach ParticleMechanics (:634-652, :669) */
+          for (long i = 0; i < nv; i++) for (int d = 0; d < 3; d++) cp[i].force[d] = 0.0;
+          continue;
+        }
         for (long i = 0; i < nv; i++) for (int d = 0; d < 3; d++) { pos[3 * i + d] = cp[i].position[d]; vel[3 * i + d] = cp[i].v[d]; frc[3 * i + d] = 0.0; }
         orc_cell_forces(T, pos, vel, frc, NULL, 0x1f);
         for (long i = 0; i < nv; i++) for (int d = 0; d < 3; d++) cp[i].force[d] = frc[3 * i + d];
@@ -1013,13 +1047,13 @@ void orc_sim_repulsion(orc_sim *S, double r_const, double r_cutoff) {
   for (long p = 0; p < S->np; p++) {
     orc_particle *pt = S->particles + p;
     pt->force_repulsion[0] = pt->force_repulsion[1] = pt->force_repulsion[2] = 0.;
-    long c[3]; int ok = 1;
+    long c[3]; int ok = S->dead[p] ? 0 : 1;   /* a removed particle is in no bin */
     for (int d = 0; d < 3; d++) {
       c[d] = (long)floor(pt->position[d] + 0.5);
       if (c[d] < 0 || c[d] >= dims[d]) { if (L->periodic[d]) c[d] = ((c[d] % dims[d]) + dims[d]) % dims[d]; else ok = 0; }
     }
     next[p] = -1;
-    if (!ok) continue;
+    if (!ok || S->dead[p]) continue;
     const long b = c[2] + (long)L->nz * (c[1] + (long)L->ny * c[0]);
     if (head[b] < 0) head[b] = p; else next[tail[b]] = p;   /* insertion order = particle order, as particle_grid[index][k] */
     tail[b] = p;
@@ -1088,6 +1122,7 @@ void orc_sim_boundary_repulsion(orc_sim *S, double br_const, double br_cutoff) {
   for (long p = 0; p < S->np; p++) {
     orc_particle *pt = S->particles + p;
     long c[3]; int ok = 1;
+    if (S->dead[p]) continue;
     for (int d = 0; d < 3; d++) {
       c[d] = (long)floor(pt->position[d] + 0.5);
       if ((c[d] < 0 || c[d] >= dims[d]) && !L->periodic[d]) ok = 0;   /* not in the particle grid (:158-161) */

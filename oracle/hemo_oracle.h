@@ -133,6 +133,14 @@ typedef struct orc_sim {
   double body_force[3];     /* driver's setExternalVector after each iterate */
   int rep_enabled, rep_timescale; double rep_const, rep_cutoff;   /* setRepulsion / setRepulsionTimeScaleSeperation */
   int brep_enabled, brep_timescale; double brep_const, brep_cutoff;   /* enableBoundaryParticles (core/hemoCell.cpp:428-436) */
+  /* What advanceParticles does with a particle whose nearest node is a boundary (core/hemoCellParticleField.cpp:566-588):
+   * 0 (default) = the reference: removeParticles(1) takes that particle out (:304-321), the cell stays behind incomplete --
+   * no mechanics (:634-652), its forces zeroed at the next material step (:660-667), still spread / interpolated / advanced --
+   * until deleteIncompleteCells (:512-553; the reference calls it at writeOutput, core/hemoCell.cpp:248-252).
+   * 1 = the whole cell is removed at once (the product's HC_DELETE_CELL mode). */
+  int deletion_mode;
+  unsigned char *dead;      /* [np] 1 = this particle was removed (its record stays in place so that cell-major indexing holds) */
+  long particles_deleted;
 } orc_sim;
 
 orc_sim *orc_sim_create(orc_lattice *L, const orc_params *P);
@@ -154,6 +162,9 @@ long orc_sim_type_offset(const orc_sim *S, int type);
 void orc_sim_get(const orc_sim *S, int what, double *out);
 void orc_sim_set(orc_sim *S, int what, const double *in);
 void orc_sim_add_vertex_force(orc_sim *S, long particle, const double f[3]);
+/* HemoCellParticleField::deleteIncompleteCells (core/hemoCellParticleField.cpp:512-553); returns the cells removed */
+long orc_sim_delete_incomplete_cells(orc_sim *S);
+void orc_sim_get_alive(const orc_sim *S, unsigned char *alive);
 
 #ifdef __cplusplus
 }

@@ -62,7 +62,8 @@ class Sim(C.Structure):
                 ("particle_velocity_timescale", C.c_int), ("force_limit_enabled", C.c_int),
                 ("iter", C.c_long), ("cells_deleted", C.c_long), ("body_force", C.c_double * 3),
                 ("rep_enabled", C.c_int), ("rep_timescale", C.c_int), ("rep_const", C.c_double), ("rep_cutoff", C.c_double),
-                ("brep_enabled", C.c_int), ("brep_timescale", C.c_int), ("brep_const", C.c_double), ("brep_cutoff", C.c_double)]
+                ("brep_enabled", C.c_int), ("brep_timescale", C.c_int), ("brep_const", C.c_double), ("brep_cutoff", C.c_double),
+                ("deletion_mode", C.c_int), ("dead", C.c_void_p), ("particles_deleted", C.c_long)]
 
 
 def build():
@@ -107,6 +108,8 @@ def load():
         "orc_sim_get": (None, [SP, C.c_int, c_double_p]),
         "orc_sim_set": (None, [SP, C.c_int, c_double_p]),
         "orc_sim_add_vertex_force": (None, [SP, C.c_long, c_double_p]),
+        "orc_sim_delete_incomplete_cells": (C.c_long, [SP]),
+        "orc_sim_get_alive": (None, [SP, C.c_void_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -32,7 +32,12 @@ def test_bench_line_small_pipe(gpu):
         assert key in rf, key
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches"] == 20
-    assert rf["torch_copy_GBps_this_gpu"] > 1000 and rf["traffic"] is None                   # the PMC figure belongs to the 256^3 headline workload only
+    assert rf["copy_GBps_this_gpu"] > 1000 and rf["traffic"] is None and rf["frac_real_traffic"] is None   # the PMC figure belongs to the 256^3 headline workload only
+    # the line says what the 353 B/node convention hides: fluid-node-only rate and the share of the box the kernel visits
+    assert 0.5 < j["fluid_node_fraction"] < j["active_node_fraction"] < 1.0
+    assert abs(j["mlups_fluid_nodes"] - j["value"] * j["fluid_node_fraction"]) < 1e-6 * j["value"]
+    assert 0 < rf["frac_active_nodes"] < rf["frac"] and len(rf["kernel_build"]) == 16
+    assert "checked every step" in j["config"]["workload"]
     cb = j["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key
@@ -43,15 +48,22 @@ def test_bench_line_small_pipe(gpu):
     assert k["collide_stream_beside"]["launches"] > 0 and k["ibm_interpolate"]["launches"] == 4
 
 
-def test_bench_two_ranks_share_the_gpu_over_gloo(gpu):
-    """the N > 1 path of bench.py as the driver launches it (torch.distributed.run, one rank per GPU), rehearsed with two
-    ranks on the one GPU of the test box; RCCL refuses two ranks on one device, so the transport is gloo here
-    (HEMOCELL_DIST_BACKEND), everything else -- slab protocol, streams, timing, reduction of the result -- is the same code"""
-    env = dict(os.environ, HEMOCELL_DIST_BACKEND="gloo")
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_two_ranks_share_the_gpu(gpu, launcher):
+    """the N > 1 path of bench.py, rehearsed with two ranks on the one GPU of the test box: started plainly
+    (`python bench.py --gpus 2`, which spawns its ranks) and the way the driver starts it (torch.distributed.run, one
+    process per rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment).  RCCL refuses two ranks on one device,
+    so the data plane is the library's TCP staging here; everything else -- native slab schedule, streams, timing,
+    reduction of the result -- is the same code"""
     port = str(29700 + os.getpid() % 200)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nx", "64", "--ny", "66", "--nz", "66",
-           "--steps", "20", "--warmup", "5"]
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nx", "64", "--ny", "66", "--nz", "66", "--steps", "20", "--warmup", "5",
+            "--transport", "tcp"]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", port] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -60,3 +72,5 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(gpu):
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["lattice"] == [128, 66, 66]
     assert j["value"] > 0 and j["config"]["cells"] > 0 and "cpu_baseline" not in j      # the CPU baseline is an N = 1 item
     assert abs(j["value"] - 128 * 66 * 66 / (j["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * j["value"]
+    assert "TCP" in j["config"]["parallelism"] and j["slab_schedule"]["host_ms_per_step"] > 0
+    assert j["slab_schedule"]["records_sent_rank0"] > 0            # cells do sit at the slab faces in this packing

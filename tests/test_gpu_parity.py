@@ -463,15 +463,20 @@ def test_full_size_properties_config2(gpu):
     L.destroy()
 
 
-def test_cell_removed_when_it_reaches_the_wall(orc, gpu):
-    """advanceParticles tags a vertex whose nearest node is a boundary (core/hemoCellParticleField.cpp:571-583);
-    here and in the oracle the whole cell is then removed.  The IBM itself never lets a membrane reach a
-    no-slip wall, so one cell is given a held velocity towards the wall (velocities are only refreshed every
-    stepParticleEvery iterations); a second cell stays.  Both sides delete the same cell at the same iteration
-    and agree afterwards."""
+@pytest.mark.parametrize("mode", ["particle", "cell"])
+def test_cell_removed_when_it_reaches_the_wall(orc, gpu, mode):
+    """advanceParticles tags a particle whose nearest node is a boundary and removeParticles(1) takes it out
+    (core/hemoCellParticleField.cpp:566-588, :304-321): the cell stays behind incomplete, gets no mechanics, has its forces
+    zeroed at the next material step and keeps being spread / interpolated / advanced until deleteIncompleteCells
+    (:512-553) -- mode "particle", the default of oracle and product.  Mode "cell" removes the whole cell at once.
+    The IBM itself never lets a membrane reach a no-slip wall, so one cell is given a held velocity towards the wall
+    (velocities are only refreshed every stepParticleEvery iterations); a second cell stays.  Oracle and GPU lose the
+    same particles at the same iterations and agree afterwards; the deletion costs the GPU path no host round trip."""
     nx, ny, nz = 40, 34, 34
     mask, R = gpu.pipe_mask(nx, ny, nz)
-    Po, Lo, Lg, So, hg = _sim_pair(orc, gpu, nx, ny, nz, (1, 0, 0), mask, k_p=1000)
+    Po, Lo, Lg, So, hg = _sim_pair(orc, gpu, nx, ny, nz, (1, 0, 0), mask, k_p=1000, k_m=3)
+    So.contents.deletion_mode = 0 if mode == "particle" else 1
+    hg.cellfields.setDeletionMode(mode)
     assert _add_both(orc, So, hg, 0, (12.0, 16.5, 16.5), (90, 0, 0))
     assert _add_both(orc, So, hg, 0, (30.0, 16.5, 25.0), (90, 0, 0))      # 8.5 lu off axis towards +z
     nv = 642
@@ -479,19 +484,49 @@ def test_cell_removed_when_it_reaches_the_wall(orc, gpu):
     orc.orc_sim_iterate(So); hg.iterate(1)                                # iteration 0 interpolates
     vel = np.zeros((2 * nv, 3)); vel[nv:, 2] = 0.05
     orc.orc_sim_set(So, 1, O.dptr(vel)); hg.cellfields.velocities = vel
-    deleted_at = None
+    first_loss = None
+    alive_o = np.ones(2 * nv, dtype=np.uint8)
     for it in range(1, 400):
-        orc.orc_sim_iterate(So); hg.iterate(1)
-        assert hg.cellfields.counts()[1] * nv == So.contents.np, it
-        if deleted_at is None and So.contents.np == nv:
-            deleted_at = it
-        if deleted_at is not None and it > deleted_at + 30:
+        orc.orc_sim_iterate(So); hg.iterate(1 if it % 7 else 3)           # calls of several iterations too (side-stream schedule)
+        if it % 7 == 0:
+            orc.orc_sim_iterate(So); orc.orc_sim_iterate(So)
+        if mode == "cell":
+            assert hg.cellfields.counts()[1] * nv == So.contents.np, it
+            lost = So.contents.np == nv
+        else:
+            alive_o = np.ones(So.contents.np, dtype=np.uint8); orc.orc_sim_get_alive(So, alive_o.ctypes.data)
+            lost = not alive_o.all()
+            if it % 10 == 0 or lost:
+                assert np.array_equal(hg.cellfields.alive(), alive_o.astype(bool)), it
+        if first_loss is None and lost:
+            first_loss = it
+        if first_loss is not None and it > first_loss + 40:
             break
-    assert deleted_at is not None and 50 < deleted_at < 399
-    assert hg.cellfields.counts() == (nv, 1, 1) and So.contents.cells_deleted == 1
+    assert first_loss is not None and 20 < first_loss < 399
+    if mode == "cell":
+        assert hg.cellfields.counts() == (nv, 1, 1) and So.contents.cells_deleted == 1
+    else:
+        # the remnants are still listed: 2 cells, one incomplete, and the records leave the removed particles out
+        gone = int((alive_o == 0).sum())
+        assert 0 < gone < nv and So.contents.particles_deleted == gone
+        assert hg.cellfields.counts() == (2 * nv, 2, 0) and hg.cellfields.deletion_counts() == (0, gone, 1, gone)
+        rec = hg.cellfields.records()
+        assert len(rec) == 2 * nv - gone and (rec["cellId"] == 1).sum() == nv - gone
+        p_o, _, f_o = _oracle_state(orc, So)
+        live = alive_o.astype(bool)
+        assert np.abs(hg.cellfields.positions - p_o)[live].max() <= 1e-9
+        assert np.abs(hg.cellfields.forces[nv:][live[nv:]]).max() == 0.0 and np.abs(f_o[nv:][live[nv:]]).max() == 0.0   # zeroed, no mechanics
+        assert np.abs(hg.cellfields.forces[:nv]).max() > 0
+        assert orc.orc_sim_delete_incomplete_cells(So) == 1 and hg.cellfields.deleteIncompleteCells() == 1
+        assert hg.cellfields.counts() == (nv, 1, 1) and So.contents.np == nv
     p_o, _, _ = _oracle_state(orc, So)
     assert np.abs(hg.cellfields.positions - p_o).max() <= 1e-9
     assert hg.cellfields.cell_ids().tolist() == [0]
+    for _ in range(10):                                                   # and both carry on identically
+        orc.orc_sim_iterate(So)
+    hg.iterate(10)
+    p_o, _, _ = _oracle_state(orc, So)
+    assert np.abs(hg.cellfields.positions - p_o).max() <= 1e-9
     Lo.destroy(); Lg.destroy()
 
 
@@ -772,9 +807,13 @@ def test_error_behaviour_of_the_c_abi(gpu):
     fails(lib.hcp_vertex_stats(h.cellfields.ptr, 0, out, C.byref(n)), "what")
     with pytest.raises(gpu.capi.HcError):
         gpu.capi.check(lib.hcl_fluid_stats(L.ptr, 5, out, C.byref(n)))
-    # a multi-slab lattice cannot be stepped by the single-domain entry points
+    # a slab of a multi-rank run cannot be stepped before the ranks are connected
     L2 = gpu.Lattice(8, 8, 8, (1, 0, 0), 1.0, x0=0, nx_global=16, n_slabs=2)
-    fails(lib.hcl_collide_stream(L2.ptr, 1), "multi-slab")
+    fails(lib.hcl_collide_stream(L2.ptr, 1), "ranks connected first")
+    h2 = gpu.HemoCell(L2, P); it = C.c_long(0)
+    fails(lib.hc_iterate(L2.ptr, h2.cellfields.ptr, C.byref(it), 1, 1, 1, 1), "ranks connected first")
+    fails(lib.hcp_set_deletion_mode(h.cellfields.ptr, 7), "HC_DELETE")
+    fails(lib.hc_comm_init(3, 2, 0, b"127.0.0.1", 30000, 0, 0), "rank must be in")
     L2.destroy(); L.destroy()
 
 

@@ -41,6 +41,18 @@ inline void writeCellField3D_HDF5(HemoCell &h, HemoCellField &field, const strin
   hc_cells *c = h.cellfields->device();
   long fv = 0, nc = 0; hcp_type_range(c, (int)field.ctype, &fv, &nc);
   long nvt = 0, nct = 0; hcp_counts(c, &nvt, &nct, nullptr);
+  // the cells this rank reports: all of them on one GPU, those whose centre lies in its slab otherwise (the other holder of
+  // an envelope copy writes it; the reference writes each particle from the block that owns it)
+  vector<long> sel;
+  {
+    vector<double> V((size_t)nc), A((size_t)nc), B(6 * (size_t)nc), P(3 * (size_t)nc);
+    if (nc && global.world > 1) hc_check(hcp_cell_info(c, (int)field.ctype, V.data(), A.data(), B.data(), P.data()), "hcp_cell_info");
+    for (long k = 0; k < nc; k++) if (global.world == 1 || CellInformationFunctionals::centre_local(&h, &P[3 * (size_t)k])) sel.push_back(k);
+  }
+  const long full_nc = nc; (void)full_nc;
+  nc = (long)sel.size();
+  const int nvc = field.numVertex;
+  auto srcv = [&](long i) { return fv + sel[(size_t)(i / nvc)] * nvc + i % nvc; };   // output row -> vertex in download order
   const long n = nc * field.numVertex;
   vector<double> pos(3 * (size_t)nvt), vel(3 * (size_t)nvt), frc(3 * (size_t)nvt), comp;
   if (nvt) { hcp_download(c, 0, pos.data()); hcp_download(c, 1, vel.data()); hcp_download(c, 2, frc.data()); }
@@ -57,14 +69,14 @@ inline void writeCellField3D_HDF5(HemoCell &h, HemoCellField &field, const strin
   }
   vector<long> ids((size_t)nct); if (nct) hcp_download_cell_ids(c, ids.data());
   long first_cell = 0; for (unsigned int t = 0; t < field.ctype; t++) { long f2, n2; hcp_type_range(c, (int)t, &f2, &n2); first_cell += n2; }
-  const string fileName = dir + "/" + field.name + "." + zeroPadNumber(h.iter) + ".p.0.h5";
+  const string fileName = dir + "/" + field.name + "." + zeroPadNumber(h.iter) + ".p." + std::to_string(global.rank) + ".h5";   // one file per block (io/ParticleHdf5IO.cpp:60)
   hid_t file = H5Fcreate(fileName.c_str(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
-  double dx = Parameters::dx, dt = Parameters::dt; long it = h.iter, np_ = 1; int id = 0;
+  double dx = Parameters::dx, dt = Parameters::dt; long it = h.iter, np_ = global.world; int id = global.rank;
   H5LTset_attribute_double(file, "/", "dx", &dx, 1); H5LTset_attribute_double(file, "/", "dt", &dt, 1);
   H5LTset_attribute_long(file, "/", "iteration", &it, 1); H5LTset_attribute_int(file, "/", "processorId", &id, 1);
   H5LTset_attribute_long(file, "/", "numberOfProcessors", &np_, 1);
   const bool si = h.outputInSiUnits;
-  auto vec3 = [&](const vector<double> &src, double scale) { vector<float> o(3 * (size_t)n); for (long i = 0; i < 3 * n; i++) o[(size_t)i] = (float)(src[(size_t)(3 * fv + i)] * scale); return o; };
+  auto vec3 = [&](const vector<double> &src, double scale) { vector<float> o(3 * (size_t)n); for (long i = 0; i < n; i++) for (int d = 0; d < 3; d++) o[(size_t)(3 * i + d)] = (float)(src[(size_t)(3 * srcv(i) + d)] * scale); return o; };
   bool triangles = false, innerlinks = false;
   for (int var : field.desiredOutputVariables) {
     switch (var) {
@@ -74,14 +86,15 @@ inline void writeCellField3D_HDF5(HemoCell &h, HemoCellField &field, const strin
         vector<double> tot(frc); for (size_t i = 0; i < tot.size(); i++) tot[i] += rep[i];
         h5_write_2d(file, "Total force", vec3(tot, si ? Parameters::df : 1.0), n, 3); break; }
       case OUTPUT_FORCE_VOLUME: case OUTPUT_FORCE_AREA: case OUTPUT_FORCE_BENDING: case OUTPUT_FORCE_LINK: case OUTPUT_FORCE_VISC: case OUTPUT_FORCE_INNER_LINK: {
-        if (comp.empty() && n) { comp.resize(18 * (size_t)n); hc_check(hcp_mechanics_components(c, (int)field.ctype, comp.data()), "hcp_mechanics_components"); }
+        const long nfull = full_nc * field.numVertex;
+        if (comp.empty() && nfull) { comp.resize(18 * (size_t)nfull); hc_check(hcp_mechanics_components(c, (int)field.ctype, comp.data()), "hcp_mechanics_components"); }
         const int slot = var == OUTPUT_FORCE_VOLUME ? 0 : var == OUTPUT_FORCE_AREA ? 1 : var == OUTPUT_FORCE_BENDING ? 2 : var == OUTPUT_FORCE_LINK ? 3 : var == OUTPUT_FORCE_VISC ? 4 : 5;
         static const char *names[6] = {"Volume force", "Area force", "Bending force", "Link force", "Viscous force", "Inner link force"};
-        vector<float> o(3 * (size_t)n); for (long i = 0; i < 3 * n; i++) o[(size_t)i] = (float)(comp[(size_t)(slot * 3 * n + i)] * (si ? Parameters::df : 1.0));
+        vector<float> o(3 * (size_t)n); for (long i = 0; i < n; i++) for (int d = 0; d < 3; d++) o[(size_t)(3 * i + d)] = (float)(comp[(size_t)(slot * 3 * nfull + 3 * (srcv(i) - fv) + d)] * (si ? Parameters::df : 1.0));
         h5_write_2d(file, names[slot], o, n, 3); break; }
       case OUTPUT_FORCE_REPULSION: h5_write_2d(file, "Repulsion force", vec3(rep, si ? Parameters::df : 1.0), n, 3); break;
       case OUTPUT_VERTEX_ID: { vector<float> o((size_t)n); for (long i = 0; i < n; i++) o[(size_t)i] = (float)(i % field.numVertex); h5_write_2d(file, "Vertex Id", o, n, 1); break; }
-      case OUTPUT_CELL_ID: { vector<float> o((size_t)n); for (long i = 0; i < n; i++) o[(size_t)i] = (float)ids[(size_t)(first_cell + i / field.numVertex)]; h5_write_2d(file, "Cell Id", o, n, 1); break; }
+      case OUTPUT_CELL_ID: { vector<float> o((size_t)n); for (long i = 0; i < n; i++) o[(size_t)i] = (float)ids[(size_t)(first_cell + sel[(size_t)(i / field.numVertex)])]; h5_write_2d(file, "Cell Id", o, n, 1); break; }
       case OUTPUT_RES_TIME: h5_write_2d(file, "Res Time", vector<float>((size_t)n, 0.f), n, 1); break;
       case OUTPUT_TRIANGLES: triangles = true; break;
       case OUTPUT_INNER_LINKS: innerlinks = true; break;
@@ -109,18 +122,18 @@ inline void writeCellField3D_HDF5(HemoCell &h, HemoCellField &field, const strin
 inline void writeFluidField_HDF5(HemoCell &h, const string &dir) {
   if (h.fluidOutputs.empty()) return;
   auto *L = h.lattice; hc_lattice *d = L->device();
-  const plint nx = L->nx, ny = L->ny, nz = L->nz;
+  const plint nx = L->nxl, ny = L->ny, nz = L->nz, x0 = L->x0;   // this rank's block
   const size_t nn = (size_t)nx * ny * nz;
   vector<double> rho(nn), u(3 * nn);
   hc_check(hcl_download_rho_u(d, rho.data(), u.data()), "hcl_download_rho_u");
-  const string fileName = dir + "/Fluid." + zeroPadNumber(h.iter) + ".p.0.h5";
+  const string fileName = dir + "/Fluid." + zeroPadNumber(h.iter) + ".p." + std::to_string(global.rank) + ".h5";
   hid_t file = H5Fcreate(fileName.c_str(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
-  double dx = Parameters::dx, dt = Parameters::dt; long it = h.iter; int id = 0;
+  double dx = Parameters::dx, dt = Parameters::dt; long it = h.iter; int id = global.rank;
   H5LTset_attribute_double(file, "/", "dx", &dx, 1); H5LTset_attribute_double(file, "/", "dt", &dt, 1);
   H5LTset_attribute_long(file, "/", "iteration", &it, 1); H5LTset_attribute_int(file, "/", "processorId", &id, 1);
   const hsize_t Nx = nx + 2, Ny = ny + 2, Nz = nz + 2;   // one-node envelope on each side for paraview
   int ncells = (int)(Nx * Ny * Nz); int sub[3] = {(int)Nz, (int)Ny, (int)Nx};
-  float dxdydz[3] = {1.f, 1.f, 1.f}, rel[3] = {-1.5f, -1.5f, -1.5f};
+  float dxdydz[3] = {1.f, 1.f, 1.f}, rel[3] = {-1.5f, -1.5f, (float)x0 - 1.5f};   // {z, y, x} of the block's first node - 1.5 (io/FluidHdf5IO.hh:112-118)
   const bool si = h.outputInSiUnits;
   if (si) for (int k = 0; k < 3; k++) { rel[k] *= (float)Parameters::dx; dxdydz[k] = (float)Parameters::dx; }
   H5LTset_attribute_int(file, "/", "numberOfCells", &ncells, 1); H5LTset_attribute_int(file, "/", "subdomainSize", sub, 3);
@@ -129,7 +142,7 @@ inline void writeFluidField_HDF5(HemoCell &h, const string &dir) {
   auto write4 = [&](const string &name, int C, const std::function<float(size_t, int)> &val) {
     vector<float> out((size_t)(Nx * Ny * Nz) * C); size_t o = 0;
     for (plint z = -1; z <= nz; z++) for (plint y = -1; y <= ny; y++) for (plint x = -1; x <= nx; x++) {
-      const size_t k = ((size_t)src(x, nx, L->per.p[0]) * ny + src(y, ny, L->per.p[1])) * nz + src(z, nz, L->per.p[2]);
+      const size_t k = ((size_t)src(x, nx, L->per.p[0] && L->world == 1) * ny + src(y, ny, L->per.p[1])) * nz + src(z, nz, L->per.p[2]);   // a slab's x-envelope repeats its face
       for (int cidx = 0; cidx < C; cidx++) out[o++] = val(k, cidx);
     }
     hsize_t dim[4] = {Nz, Ny, Nx, (hsize_t)C}, chunk[4] = {std::min<hsize_t>(1000, Nz), std::min<hsize_t>(1000, Ny), std::min<hsize_t>(1000, Nx), (hsize_t)C};
@@ -143,7 +156,7 @@ inline void writeFluidField_HDF5(HemoCell &h, const string &dir) {
     if (var == OUTPUT_VELOCITY) write4("Velocity", 3, [&](size_t k, int cidx) { return (float)(u[3 * k + cidx] * (si ? Parameters::dx / Parameters::dt : 1.0)); });
     else if (var == OUTPUT_FORCE) write4("Force", 3, [&](size_t, int cidx) { return (float)(L->body[cidx] * (si ? Parameters::df : 1.0)); });
     else if (var == OUTPUT_DENSITY) write4("Density", 1, [&](size_t k, int) { return (float)(rho[k] * (si ? Parameters::df / (Parameters::dx * Parameters::dx) : 1.0)); });
-    else if (var == OUTPUT_BOUNDARY) write4("Boundary", 1, [&](size_t k, int) { return L->mask[k] ? 1.f : 0.f; });
+    else if (var == OUTPUT_BOUNDARY) write4("Boundary", 1, [&](size_t k, int) { return L->mask[k + (size_t)x0 * ny * nz] ? 1.f : 0.f; });
   }
   H5Fclose(file);
 }

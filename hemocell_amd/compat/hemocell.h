@@ -448,9 +448,9 @@ class HemoCell {
     } else hlog_instance().to_stdout = false;   // the log is rank 0's (config/logfile.h)
     hc_comm_barrier();
     hlog << "(HemoCell) (Config) reading " << configFileName << endl;
-    if (global.world > 1) hlog << "(HemoCell) (GPU backend) " << global.world << " ranks: one x-slab per rank and GPU, " << (tr == HC_TRANSPORT_RCCL ? "RCCL point-to-point" : "host-staged (ranks share a GPU)") << " neighbour exchange" << endl;
+    if (global.world > 1) hlog << "(HemoCell) (GPU backend) " << global.world << " atomic-blocks: one x-slab per rank and GPU, " << (tr == HC_TRANSPORT_RCCL ? "RCCL point-to-point" : "host-staged (ranks share a GPU)") << " neighbour exchange" << endl;
   }
-  ~HemoCell() { delete cellfields; delete lattice; delete cfg; hc_comm_finalize(); global.hemoCellInitialized = false; }   // core/hemoCell.cpp:97-127: the facade owns the driver's lattice
+  ~HemoCell() { flush(); hc_synchronize(); delete cellfields; delete lattice; delete cfg; hc_comm_finalize(); global.hemoCellInitialized = false; }   // core/hemoCell.cpp:97-127: the facade owns the driver's lattice
 
   void latticeEquilibrium(T rho, hemo::Array<T, 3> vel) { lattice->eq_rho = rho; for (int d = 0; d < 3; d++) lattice->eq_u[d] = vel[d]; lattice->dirty_layout = true; }
   void initializeCellfield() { cellfields = new HemoCellFields(*this); }
@@ -473,10 +473,12 @@ class HemoCell {
   void setFluidOutputs(vector<int> outputs) { fluidOutputs = outputs; }
   void setMaterialTimeScaleSeparation(string name, unsigned int separation) {
     hlog << "(HemoCell) (Timescale Seperation) Setting seperation of " << name << " to " << separation << " timesteps" << endl;
+    flush();
     (*cellfields)[name]->timescale = separation;
   }
   void setParticleVelocityUpdateTimeScaleSeparation(unsigned int separation) {
     hlog << "(HemoCell) (Timescale separation) Setting update separation of all particles to " << separation << " timesteps" << endl;
+    flush();
     cellfields->particleVelocityUpdateTimescale = separation;
   }
   void setRepulsion(T repulsionConstant, T repulsionCutoff) {   // core/hemoCell.cpp:420-426 (cut-off in micrometres)
@@ -502,18 +504,40 @@ class HemoCell {
   void loadCheckPoint();
   void saveCheckPoint();
   void writeOutput();
+  // HemoCell::iterate() (core/hemoCell.cpp:299-376).  A driver calls it once per iteration; the device runs fastest when it is
+  // handed several iterations at once (advance, mechanics and the next spread then run beside the collide, DESIGN.md section
+  // 4a).  So the call only queues the iteration; the queue is run -- one hc_iterate for all of it -- before anything can
+  // observe or change the state: every path to the device goes through lattice->device() / cellfields->device(), which
+  // flush first.  What a driver sees (iter, statistics, output, forces it adds between iterations) is unchanged.
   void iterate() {
-    hc_cells *c = cellfields->device();
-    if (boundaryRepulsionEnabled && !boundaryRepulsionPushed) { hc_check(hcp_set_boundary_repulsion(c, boundaryRepulsionConstant_, boundaryRepulsionCutoff_, (int)boundaryRepulsionTimescale), "hcp_set_boundary_repulsion"); boundaryRepulsionPushed = true; }
-    if (repulsionEnabled && !repulsionPushed) { hc_check(hcp_set_repulsion(c, repulsionConstant_, repulsionCutoff_, (int)repulsionTimescale), "hcp_set_repulsion"); repulsionPushed = true; }
-    long it = iter;
+    if (!lattice->before_access) lattice->before_access = [this] { flush(); };
+    if (!pending) {   // first queued iteration: make sure everything it needs exists and settings are pushed
+      hc_cells *c = cellfields->device();
+      if (boundaryRepulsionEnabled && !boundaryRepulsionPushed) { hc_check(hcp_set_boundary_repulsion(c, boundaryRepulsionConstant_, boundaryRepulsionCutoff_, (int)boundaryRepulsionTimescale), "hcp_set_boundary_repulsion"); boundaryRepulsionPushed = true; }
+      if (repulsionEnabled && !repulsionPushed) { hc_check(hcp_set_repulsion(c, repulsionConstant_, repulsionCutoff_, (int)repulsionTimescale), "hcp_set_repulsion"); repulsionPushed = true; }
+      lattice->device();
+      queued_timescale = cellfields->particleVelocityUpdateTimescale;
+    }
     const bool particle_step = iter % cellfields->particleVelocityUpdateTimescale == 0;
-    hc_check(hc_iterate(lattice->device(), c, &it, 1, (int)cellfields->particleVelocityUpdateTimescale, /*force_limit=*/1, /*compaction look-up cadence=*/1), "iterate");
-    if (global.cellsDeletedInfo && particle_step) cellfields->deleteIncompleteCells(true);   // core/hemoCell.cpp:360-363
+    pending++; iter++;
+    // run at once where the reference does something between two iterations that the queue would skip, and bound the queue
+    if ((global.cellsDeletedInfo && particle_step) || pending >= 1024) {
+      flush();
+      if (global.cellsDeletedInfo && particle_step) cellfields->deleteIncompleteCells(true);   // core/hemoCell.cpp:360-363
+    }
+  }
+  void flush() {
+    if (!pending || flushing) return;
+    flushing = true;
+    long it = (long)iter - (long)pending;
+    const int n = (int)pending;
+    pending = 0;
+    hc_check(hc_iterate(lattice->device_now(), cellfields->dev, &it, n, (int)queued_timescale, /*force_limit=*/1, /*compaction look-up cadence=*/1), "iterate");
     lattice->mark_stepped();
     cellfields->particleField.invalidate();
-    iter = (unsigned int)it;
+    flushing = false;
   }
+  unsigned int pending = 0, queued_timescale = 1; bool flushing = false;
 
   bool outputInSiUnits = true;
   bool repulsionEnabled = false, repulsionPushed = false; T repulsionConstant_ = 0, repulsionCutoff_ = 0; unsigned int repulsionTimescale = 1;
@@ -597,6 +621,7 @@ inline CommonCellConstants CommonCellConstants::CommonCellConstantsConstructor(H
 }
 
 inline hc_cells *HemoCellFields::device() {
+  hemocell.flush();   // queued iterations run before anybody looks at or edits the cells
   if (!dev) { hc_check(hcp_create(&dev, hemocell.lattice->device(), &Parameters::raw()), "hcp_create"); hemocell.lattice->cells_bound = true; }
   if (!types_bound) {
     for (auto *f : cellFields) {
@@ -610,6 +635,48 @@ inline hc_cells *HemoCellFields::device() {
   }
   return dev;
 }
+
+// ---- HemoCellParticleField: host view of this rank's particles (core/hemoCellParticleField.h:39-207)
+inline void HemoCellParticleField::refresh() {
+  if (fresh_iter == (long)fields.hemocell.iter && fresh_iter >= 0) return;
+  hc_cells *c = fields.device();
+  long nvt = 0, miss = 0; hcp_counts(c, &nvt, nullptr, nullptr); hcp_deletion_counts(c, nullptr, nullptr, nullptr, &miss);
+  vector<HemoCellParticle::serializeValues_t> rec((size_t)(nvt - miss));
+  if (!rec.empty()) hc_check(hcp_download_records(c, rec.data(), (long)rec.size()), "hcp_download_records");
+  particles.clear(); particles.reserve(rec.size());
+  for (auto &r : rec) particles.emplace_back(r);
+  auto *L = fields.hemocell.lattice;
+  localDomain = plb::Box3D(L->x0, L->x0 + L->nxl - 1, 0, L->ny - 1, 0, L->nz - 1); boundingBox = localDomain;
+  // update_ppc / update_lpc / update_ppt (core/hemoCellParticleField.cpp:395-467)
+  _particles_per_cell.clear(); _lpc.clear(); _particles_per_type.assign(fields.size(), vector<unsigned int>());
+  for (unsigned int i = 0; i < particles.size(); i++) {
+    const auto &sv = particles[i].sv;
+    auto &v = _particles_per_cell[(int)sv.cellId];
+    if (v.empty()) v.assign((size_t)fields[sv.celltype]->numVertex, -1);
+    v[sv.vertexId] = (int)i;
+    if (isContainedABS(sv.position, localDomain) || global.world == 1) _lpc[(int)sv.cellId] = true;
+    _particles_per_type[sv.celltype].push_back(i);
+  }
+  fresh_iter = (long)fields.hemocell.iter;
+}
+// hand edited records back to the device (complete cells only, as the reference requires before mechanics)
+inline void HemoCellParticleField::upload() {
+  vector<HemoCellParticle::serializeValues_t> rec; rec.reserve(particles.size());
+  for (auto &p : particles) rec.push_back(p.sv);
+  hc_check(hcp_upload_records(fields.device(), rec.data(), (long)rec.size()), "hcp_upload_records");
+  fresh_iter = -1;
+}
+inline int HemoCellParticleField::deleteIncompleteCells(bool verbose) {
+  long n = 0; hc_check(hcp_delete_incomplete_cells(fields.device(), &n), "hcp_delete_incomplete_cells");
+  if (verbose && n) hlog << "(HemoCell) (Delete Cells) " << n << " incomplete cell(s) removed: a particle of theirs had reached a wall" << endl;   // issueWarning, :497-503
+  fresh_iter = -1;
+  return (int)n;
+}
+inline void HemoCellFields::spreadParticleForce() { hc_check(hcp_spread(device(), 1), "hcp_spread"); }
+inline void HemoCellFields::interpolateFluidVelocity() { hc_check(hcp_interpolate(device()), "hcp_interpolate"); particleField.invalidate(); }
+inline void HemoCellFields::advanceParticles() { hc_check(hcp_advance(device(), 0), "hcp_advance"); particleField.invalidate(); }
+inline void HemoCellFields::applyConstitutiveModel(bool forced) { hc_check(hcp_mechanics(device(), (long)hemocell.iter, forced ? 1 : 0), "hcp_mechanics"); particleField.invalidate(); }
+inline void HemoCellFields::deleteIncompleteCells(bool verbose) { particleField.deleteIncompleteCells(verbose); }
 
 // io/readPositionsBloodCells.cpp:205-361: "<name>.pos": N, then x y z (um) rx ry rz (deg) per cell
 inline void HemoCell::loadParticles() {
@@ -669,64 +736,64 @@ inline void HemoCell::loadParticles() {
 // The reference writes Palabos' own parallelIO dumps plus checkpoint.xml (a copy of the config under a <Checkpoint>
 // root with the iteration); the binary format here is this back end's own: populations in the reference node
 // order, then per type the cell ids and the vertex position / velocity / force arrays.
+inline string checkpoint_file(const string &dir) { return dir + (global.world > 1 ? "/checkpoint." + std::to_string(global.rank) + ".bin" : string("/checkpoint.bin")); }
+
 inline void HemoCell::saveCheckPoint() {
   const string dir = outDir + "/checkpoint";
-  mkdir(dir.c_str(), 0755);
-  rename((dir + "/checkpoint.bin").c_str(), (dir + "/checkpoint.bin.old").c_str());   // :283-290 keeps the previous one
-  rename((dir + "/checkpoint.xml").c_str(), (dir + "/checkpoint.xml.old").c_str());
+  if (global.rank == 0) {
+    mkdir(dir.c_str(), 0755);
+    rename((dir + "/checkpoint.xml").c_str(), (dir + "/checkpoint.xml.old").c_str());
+  }
+  hc_comm_barrier();
+  rename(checkpoint_file(dir).c_str(), (checkpoint_file(dir) + ".old").c_str());   // :283-290 keeps the previous one
   hc_lattice *d = lattice->device(); hc_cells *c = cellfields->device();
-  const size_t n = (size_t)lattice->nx * lattice->ny * lattice->nz;
+  const size_t n = (size_t)lattice->nxl * lattice->ny * lattice->nz;
   vector<double> f(n * HC_Q);
   hc_check(hcl_download_populations(d, f.data()), "hcl_download_populations");
-  std::ofstream o((dir + "/checkpoint.bin").c_str(), std::ios::binary);
-  const long hdr[6] = {0x48434b50, (long)iter, lattice->nx, lattice->ny, lattice->nz, (long)cellfields->size()};
+  std::ofstream o(checkpoint_file(dir).c_str(), std::ios::binary);
+  const long hdr[8] = {0x48434b51, (long)iter, lattice->nx, lattice->ny, lattice->nz, (long)cellfields->size(), lattice->x0, lattice->nxl};
   o.write((const char *)hdr, sizeof(hdr));
   o.write((const char *)f.data(), (std::streamsize)(f.size() * sizeof(double)));
-  long nvt = 0, nct = 0; hcp_counts(c, &nvt, &nct, nullptr);
-  vector<long> ids((size_t)nct); if (nct) hcp_download_cell_ids(c, ids.data());
-  o.write((const char *)&nct, sizeof(long)); o.write((const char *)ids.data(), (std::streamsize)(ids.size() * sizeof(long)));
-  for (unsigned int t = 0; t < cellfields->size(); t++) { long fv, nc; hcp_type_range(c, (int)t, &fv, &nc); o.write((const char *)&nc, sizeof(long)); }
-  for (int what = 0; what < 3; what++) {
-    vector<double> a(3 * (size_t)nvt); if (nvt) hc_check(hcp_download(c, what, a.data()), "hcp_download");
-    o.write((const char *)a.data(), (std::streamsize)(a.size() * sizeof(double)));
+  // the particles in the reference's own record (core/hemoCellParticle.h:45-63): position, velocity, force AND
+  // force_repulsion, so that a resume with repulsionTimescale > 1 continues bit for bit
+  long nvt = 0, miss = 0; hcp_counts(c, &nvt, nullptr, nullptr); hcp_deletion_counts(c, nullptr, nullptr, nullptr, &miss);
+  long nrec = nvt - miss;
+  vector<HemoCellParticle::serializeValues_t> rec((size_t)nrec);
+  if (nrec) hc_check(hcp_download_records(c, rec.data(), nrec), "hcp_download_records");
+  o.write((const char *)&nrec, sizeof(long));
+  o.write((const char *)rec.data(), (std::streamsize)(rec.size() * sizeof(rec[0])));
+  if (global.rank == 0) {
+    std::ofstream x((dir + "/checkpoint.xml").c_str());
+    x << "<?xml version=\"1.0\" ?>\n<Checkpoint>\n<General><Iteration>" << iter << "</Iteration><OutDirectory>" << outDir << "</OutDirectory></General>\n";
+    std::ifstream cfgin(configFile.c_str()); string line; bool first = true;
+    while (std::getline(cfgin, line)) { if (first && line.find("<?xml") != string::npos) { first = false; continue; } x << line << "\n"; }
+    x << "</Checkpoint>\n";
   }
-  std::ofstream x((dir + "/checkpoint.xml").c_str());
-  x << "<?xml version=\"1.0\" ?>\n<Checkpoint>\n<General><Iteration>" << iter << "</Iteration><OutDirectory>" << outDir << "</OutDirectory></General>\n";
-  std::ifstream cfgin(configFile.c_str()); string line; bool first = true;
-  while (std::getline(cfgin, line)) { if (first && line.find("<?xml") != string::npos) { first = false; continue; } x << line << "\n"; }
-  x << "</Checkpoint>\n";
   hlog << "(HemoCell) (saveCheckPoint) saved iteration " << iter << " to " << dir << endl;
 }
 
 inline void HemoCell::loadCheckPoint() {
   const string dir = outDir + "/checkpoint";
-  std::ifstream in((dir + "/checkpoint.bin").c_str(), std::ios::binary);
-  if (!in.is_open()) { hlog << "(HemoCell) (loadCheckPoint) " << dir << "/checkpoint.bin not found" << endl; std::exit(1); }
-  long hdr[6]; in.read((char *)hdr, sizeof(hdr));
-  if (hdr[0] != 0x48434b50 || hdr[2] != lattice->nx || hdr[3] != lattice->ny || hdr[4] != lattice->nz || hdr[5] != (long)cellfields->size()) {
-    hlog << "(HemoCell) (loadCheckPoint) checkpoint does not match this case (lattice size / cell types)" << endl; std::exit(1);
-  }
+  std::ifstream in(checkpoint_file(dir).c_str(), std::ios::binary);
+  if (!in.is_open()) { hlog << "(HemoCell) (loadCheckPoint) " << checkpoint_file(dir) << " not found" << endl; std::exit(1); }
   hc_lattice *d = lattice->device(); hc_cells *c = cellfields->device();
-  const size_t n = (size_t)lattice->nx * lattice->ny * lattice->nz;
+  long hdr[8]; in.read((char *)hdr, sizeof(hdr));
+  if (hdr[0] != 0x48434b51 || hdr[2] != lattice->nx || hdr[3] != lattice->ny || hdr[4] != lattice->nz || hdr[5] != (long)cellfields->size() || hdr[6] != lattice->x0 || hdr[7] != lattice->nxl) {
+    hlog << "(HemoCell) (loadCheckPoint) checkpoint does not match this case (lattice size / cell types / number of ranks)" << endl; std::exit(1);
+  }
+  const size_t n = (size_t)lattice->nxl * lattice->ny * lattice->nz;
   vector<double> f(n * HC_Q);
   in.read((char *)f.data(), (std::streamsize)(f.size() * sizeof(double)));
   hc_check(hcl_upload_populations(d, f.data()), "hcl_upload_populations");
-  long nct = 0; in.read((char *)&nct, sizeof(long));
-  vector<long> ids((size_t)nct); in.read((char *)ids.data(), (std::streamsize)(ids.size() * sizeof(long)));
-  vector<long> per_type(cellfields->size()); for (auto &v : per_type) in.read((char *)&v, sizeof(long));
-  // recreate the cells (placement is overwritten by the stored state right below)
-  long k = 0, nvt = 0;
-  for (unsigned int t = 0; t < cellfields->size(); t++)
-    for (long i = 0; i < per_type[t]; i++, k++) {
-      const double centre[3] = {lattice->nx * 0.5, lattice->ny * 0.5, lattice->nz * 0.5}, ang[3] = {0, 0, 0}; int placed = 0;
-      hc_check(hcp_add_cell_unchecked(c, (int)t, ids[(size_t)k], centre, ang), "hcp_add_cell_unchecked");
-      (void)placed; nvt += (*cellfields)[t]->numVertex;
-    }
+  long nrec = 0; in.read((char *)&nrec, sizeof(long));
+  vector<HemoCellParticle::serializeValues_t> rec((size_t)nrec);
+  in.read((char *)rec.data(), (std::streamsize)(rec.size() * sizeof(rec[0])));
+  // a repulsion the driver enabled has to exist before the records arrive, or their force_repulsion would be dropped
+  if (boundaryRepulsionEnabled && !boundaryRepulsionPushed) { hc_check(hcp_set_boundary_repulsion(c, boundaryRepulsionConstant_, boundaryRepulsionCutoff_, (int)boundaryRepulsionTimescale), "hcp_set_boundary_repulsion"); boundaryRepulsionPushed = true; }
+  if (repulsionEnabled && !repulsionPushed) { hc_check(hcp_set_repulsion(c, repulsionConstant_, repulsionCutoff_, (int)repulsionTimescale), "hcp_set_repulsion"); repulsionPushed = true; }
+  hc_check(hcp_upload_records(c, rec.data(), nrec), "hcp_upload_records");
+  long nct = 0; hcp_counts(c, nullptr, &nct, nullptr);
   cellfields->number_of_cells = (int)nct;
-  for (int what = 0; what < 3; what++) {
-    vector<double> a(3 * (size_t)nvt); in.read((char *)a.data(), (std::streamsize)(a.size() * sizeof(double)));
-    if (nvt) hc_check(hcp_upload(c, what, a.data()), "hcp_upload");
-  }
   iter = (unsigned int)hdr[1];
   lattice->mark_stepped();
   hlog << "(HemoCell) (loadCheckPoint) resumed at iteration " << iter << endl;
@@ -885,10 +952,11 @@ namespace hemo {
 
 // core/hemoCell.cpp:221-287: <out>/hdf5/<iter>/ with one file per cell type plus the fluid file, and the CSV summary
 inline void HemoCell::writeOutput() {
+  cellfields->deleteIncompleteCells(global.cellsDeletedInfo);   // core/hemoCell.cpp:248-252: the writers expect whole cells
 #ifdef HEMOCELL_WITH_HDF5
-  mkdir((outDir + "/hdf5").c_str(), 0755);
   const string dir = outDir + "/hdf5/" + zeroPadNumber(iter);
-  mkdir(dir.c_str(), 0755);
+  if (global.rank == 0) { mkdir((outDir + "/hdf5").c_str(), 0755); mkdir(dir.c_str(), 0755); }
+  hc_comm_barrier();
   hlog << "(HemoCell) (Output) writing output at timestep " << iter << " (" << iter * Parameters::dt << " s)" << endl;
   for (unsigned int t = 0; t < cellfields->size(); t++) writeCellField3D_HDF5(*this, *(*cellfields)[t], dir);
   writeFluidField_HDF5(*this, dir);

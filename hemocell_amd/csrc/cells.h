@@ -93,6 +93,7 @@ struct LatView {
   int per_y, per_z;
   int nx_global;
   uint8_t *dirty; uint8_t epoch;   // dirty map of the force buffer spread adds to (see common.h)
+  const uint8_t *wallbrick; int nby, nbz;   // wall proximity per 8^3 brick (see common.h)
 };
 
 inline LatView make_view(const hc_lattice *L) {
@@ -101,6 +102,7 @@ inline LatView make_view(const hc_lattice *L) {
   v.x0 = L->x0; v.wrap_x = (L->n_slabs == 1 && L->periodic[0]) ? 1 : 0; v.halo_x = L->n_slabs > 1 ? 1 : 0;
   v.per_y = L->periodic[1]; v.per_z = L->periodic[2]; v.nx_global = L->nx_global;
   v.dirty = L->fdirty[L->fcur]; v.epoch = L->fepoch[L->fcur];
+  v.wallbrick = L->wallbrick; v.nby = L->nby; v.nbz = L->nbz;
   return v;
 }
 

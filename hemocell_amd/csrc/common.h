@@ -100,6 +100,9 @@ struct hc_lattice {
   // Epochs are never cleared (no races); an aliased stale epoch only causes a harmless extra read / zeroing.
   uint8_t *fdirty[3];
   uint8_t fepoch[3];
+  // one byte per 8 x 8 x 8 brick of the padded lattice: 1 = the brick holds a non-fluid node or touches a face that stencils
+  // cannot cross (the IBM kernels skip the mask look-ups for cells whose tile meets no such brick)
+  uint8_t *wallbrick; int nbx, nby, nbz;
   uint8_t *mask;         // [npad]
   std::vector<uint8_t> hmask;  // host copy (cell placement tests against it)
   double body[3];

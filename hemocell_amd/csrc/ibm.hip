@@ -5,6 +5,7 @@
 //   core/hemoCellParticleField.cpp:841-863        spreadParticleForce
 //   core/hemoCellParticleField.cpp:819-839        interpolateFluidVelocity
 #include "cells.h"
+#include <cstdlib>
 
 namespace {
 
@@ -218,7 +219,7 @@ __device__ __forceinline__ void tile_stencil(const Tile &t, const unsigned char 
       for (int k = 0; k < 2; k++) {
         const int idx = i * 4 + j * 2 + k;
         const double weight = phi2(px - (double)(b[0] + i)) * phi2(py - (double)(b[1] + j)) * phi2(pz - (double)(b[2] + k));
-        const bool adm = (weight != 0.0) && (mt[o.base + i * sx + j * sy + k] == 0);
+        const bool adm = (weight != 0.0) && (!mt || mt[o.base + i * sx + j * sy + k] == 0);   // mt == nullptr: no wall anywhere near this cell
         if (adm) { total += weight; o.adm |= 1u << idx; }
         o.w[idx] = adm ? weight : 0.0;
       }
@@ -227,11 +228,40 @@ __device__ __forceinline__ void tile_stencil(const Tile &t, const unsigned char 
   for (int idx = 0; idx < 8; idx++) o.w[idx] *= coeff;
 }
 
-// shared prologue of the two cell kernels: positions -> registers, tile, mask tile, stencils.
+// Is every node of the tile an ordinary fluid node inside the domain?  Then interpolationCoefficientsPhi2 admits every node
+// with a non-zero weight and the mask need not be looked at (most cells of a vessel are nowhere near its wall).  Answered
+// from one byte per 8 x 8 x 8 brick of the padded lattice (hc_lattice::wallbrick: set when the brick holds a non-fluid node or
+// touches a face the stencils cannot cross); a tile covers at most 4 x 4 x 4 bricks, one per lane of wave 0.
+__device__ __forceinline__ bool tile_is_clear(const LatView &v, const Tile &t, int *s_near) {
+  const int n[3] = {v.nx, v.ny, v.nz};
+  bool inside = v.wallbrick != nullptr;
+  int b0[3], nb[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const int lo = a == 0 ? t.ow[0] + HALO : t.ow[a], hi = lo + t.e[a] - 1, lim = a == 0 ? v.nx + 2 * HALO : n[a];   // x in padded planes
+    inside = inside && lo >= 0 && hi < lim && (a != 0 || !v.wrap_x || (t.ow[0] >= 0 && t.ow[0] + t.e[0] <= v.nx));
+    b0[a] = lo >> 3; nb[a] = (hi >> 3) - b0[a] + 1;
+  }
+  if (!inside) return false;   // uniform: the tile wraps around a periodic face or leaves the addressable range
+  if (threadIdx.x < 64) {
+    const int l = threadIdx.x;
+    bool near = false;
+    if (l < nb[0] * nb[1] * nb[2]) {
+      const int bz = l % nb[2], by = (l / nb[2]) % nb[1], bx = l / (nb[2] * nb[1]);
+      near = v.wallbrick[((long)(b0[0] + bx) * v.nby + (b0[1] + by)) * v.nbz + (b0[2] + bz)] != 0;
+    }
+    const unsigned long long any = __ballot(near);
+    if (l == 0) *s_near = any != 0ull;
+  }
+  __syncthreads();
+  return *s_near == 0;
+}
+
+// shared prologue of the two cell kernels: positions -> registers, tile, mask tile (only near walls), stencils.
 // returns false (uniformly) when the cell does not fit the tile and the caller must take the fallback path
 // dead: removed particles of an INCOMPLETE cell (null for a complete one); they take no part in anything
 __device__ __forceinline__ bool cell_prologue(const LatView &v, int nv, long base, const double *px, const double *py, const double *pz,
-                                              const unsigned char *dead, int *s_red, unsigned char *mt, Tile &t, VStencil vs[NVPT]) {
+                                              const unsigned char *dead, int *s_red, int *s_near, unsigned char *mt, Tile &t, VStencil vs[NVPT]) {
   const int tid = threadIdx.x, nth = blockDim.x;
   double p[NVPT][3]; int b[NVPT][3]; bool live[NVPT];
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
@@ -248,13 +278,16 @@ __device__ __forceinline__ bool cell_prologue(const LatView &v, int nv, long bas
   }
   block_bbox(lo, hi, s_red, t);
   if (!tile_finish(v, t) || nv > NVPT * nth) return false;
+  const bool clear = tile_is_clear(v, t, s_near);   // uniform
+  if (!clear) {
 #pragma unroll 4
-  for (int i = tid; i < t.vol; i += nth) mt[i] = tile_mask(v, t, i);
-  __syncthreads();
+    for (int i = tid; i < t.vol; i += nth) mt[i] = tile_mask(v, t, i);
+    __syncthreads();
+  }
 #pragma unroll
   for (int j = 0; j < NVPT; j++) {
     vs[j].adm = 0; vs[j].base = 0;
-    if (live[j]) tile_stencil(t, mt, p[j][0], p[j][1], p[j][2], b[j], vs[j]);
+    if (live[j]) tile_stencil(t, clear ? nullptr : mt, p[j][0], p[j][1], p[j][2], b[j], vs[j]);
   }
   return true;
 }
@@ -264,15 +297,31 @@ __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv,
                                                               double *F, int limit_on, double f_limit, int xcd_ranges, const int *tag, const unsigned char *vdead) {
   __shared__ double tile[TILE_CAP];
   __shared__ unsigned char mt[TILE_CAP];
-  __shared__ int s_red[6 * MAXW];
+  __shared__ int s_red[6 * MAXW], s_near;
   const int tid = threadIdx.x, nth = blockDim.x;
   const int cell = xcd_ranges ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   const int state = tag[cell];
   if (state == 1) return;                                        // the cell is gone
   const unsigned char *dead = state == 2 ? vdead : nullptr;      // incomplete: skip its removed particles
   const long base = (long)cell * nv;
-  // FORCE_LIMIT cap, core/hemoCellParticleField.cpp:848-852 (mutates sv.force)
-  if (limit_on) {
+  const bool in_regs = nv <= NVPT * nth;
+  // forces of this thread's vertices, loaded together with the positions; FORCE_LIMIT cap,
+  // core/hemoCellParticleField.cpp:848-852 (mutates sv.force)
+  double f[NVPT][3];
+  if (in_regs) {
+#pragma unroll
+    for (int j = 0; j < NVPT; j++) {
+      const int i = tid + j * nth;
+      f[j][0] = f[j][1] = f[j][2] = 0.0;
+      if (i < nv) {
+        f[j][0] = fx[base + i]; f[j][1] = fy[base + i]; f[j][2] = fz[base + i];
+        if (limit_on) {
+          const double mag = sqrt((f[j][0] * f[j][0] + f[j][1] * f[j][1]) + f[j][2] * f[j][2]);
+          if (mag > f_limit) { const double sc = f_limit / mag; f[j][0] *= sc; f[j][1] *= sc; f[j][2] *= sc; fx[base + i] = f[j][0]; fy[base + i] = f[j][1]; fz[base + i] = f[j][2]; }
+        }
+      }
+    }
+  } else if (limit_on) {
     for (int i = tid; i < nv; i += nth) {
       const double f0 = fx[base + i], f1 = fy[base + i], f2 = fz[base + i];
       const double mag = sqrt((f0 * f0 + f1 * f1) + f2 * f2);
@@ -280,7 +329,7 @@ __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv,
     }
   }
   Tile t; VStencil vs[NVPT];
-  if (!cell_prologue(v, nv, base, px, py, pz, dead, s_red, mt, t, vs)) {
+  if (!cell_prologue(v, nv, base, px, py, pz, dead, s_red, &s_near, mt, t, vs)) {
     // cell larger than the tile (or mesh larger than the register budget): direct global atomics
     for (int i = tid; i < nv; i += nth) {
       if (dead && dead[base + i]) continue;
@@ -299,8 +348,8 @@ __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv,
     return;
   }
   const int sy = t.e[2], sx = t.e[1] * t.e[2];
+#pragma unroll
   for (int comp = 0; comp < 3; comp++) {
-    const double *fc = comp == 0 ? fx : comp == 1 ? fy : fz;
     const double *rc = comp == 0 ? rx : comp == 1 ? ry : rz;
     double *Fc = F + (long)comp * v.npad;
     for (int i = tid; i < t.vol; i += nth) tile[i] = 0.0;
@@ -309,15 +358,18 @@ __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv,
     for (int j = 0; j < NVPT; j++) {
       const int i = tid + j * nth;
       if (i >= nv || !vs[j].adm) continue;
-      const double f = (rc ? rc[base + i] : 0.0) + fc[base + i];   // force_repulsion + force, :857-859
+      const double fv = (rc ? rc[base + i] : 0.0) + f[j][comp];   // force_repulsion + force, :857-859
 #pragma unroll
       for (int k = 0; k < 8; k++)
-        if (vs[j].adm & (1u << k)) atomicAdd(&tile[vs[j].base + (k >> 2) * sx + ((k >> 1) & 1) * sy + (k & 1)], f * vs[j].w[k]);
+        if (vs[j].adm & (1u << k)) atomicAdd(&tile[vs[j].base + (k >> 2) * sx + ((k >> 1) & 1) * sy + (k & 1)], fv * vs[j].w[k]);
     }
     __syncthreads();
     for (int i = tid; i < t.vol; i += nth) {
       const double val = tile[i];
-      if (val != 0.0) { int lx, ly, lz; const long node = tile_node(v, t, i, lx, ly, lz); v.dirty[node >> 4] = v.epoch; unsafeAtomicAdd(&Fc[node], val); }
+      if (val != 0.0) {
+        int lx, ly, lz; const long node = tile_node(v, t, i, lx, ly, lz); v.dirty[node >> 4] = v.epoch;
+        unsafeAtomicAdd(&Fc[node], val);
+      }
     }
     __syncthreads();
   }
@@ -333,7 +385,7 @@ __global__ __launch_bounds__(256) void ibm_interpolate_cell_kernel(LatView v, Po
   __shared__ __attribute__((aligned(16))) unsigned char raw[TILE_CAP > 2 * NODE_CAP ? TILE_CAP : 2 * NODE_CAP];
   unsigned char *mt = raw; unsigned short *list = reinterpret_cast<unsigned short *>(raw);
   __shared__ double ux[NODE_CAP], uy[NODE_CAP], uz[NODE_CAP];
-  __shared__ int s_red[6 * MAXW], s_count;
+  __shared__ int s_red[6 * MAXW], s_count, s_near;
   const int tid = threadIdx.x, nth = blockDim.x;
   const int cell = slots ? slots[blockIdx.x] : (xcd_ranges ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x);   // slots: only the listed cells of the type
   const int state = tag[cell];
@@ -341,7 +393,7 @@ __global__ __launch_bounds__(256) void ibm_interpolate_cell_kernel(LatView v, Po
   const unsigned char *dead = state == 2 ? vdead : nullptr;
   const long base = (long)cell * nv;
   Tile t; VStencil vs[NVPT];
-  bool tiled = cell_prologue(v, nv, base, px, py, pz, dead, s_red, mt, t, vs);
+  bool tiled = cell_prologue(v, nv, base, px, py, pz, dead, s_red, &s_near, mt, t, vs);
   const int sy = t.e[2], sx = t.e[1] * t.e[2];
   if (tiled) {
     for (int i = tid; i < t.vol; i += nth) slot[i] = FREE;

@@ -435,6 +435,30 @@ int rebuild_active_map(hc_lattice *L) {
   return HC_OK;
 }
 
+// one byte per 8 x 8 x 8 brick (see hc_lattice::wallbrick)
+int rebuild_wall_bricks(hc_lattice *L) {
+  const int NX = L->nx + 2 * HALO, ny = L->ny, nz = L->nz;
+  std::vector<uint8_t> flag((size_t)L->nbx * L->nby * L->nbz, 0);
+  for (int bx = 0; bx < L->nbx; bx++)
+    for (int by = 0; by < L->nby; by++)
+      for (int bz = 0; bz < L->nbz; bz++) {
+        bool near = false;
+        // faces no stencil crosses: the ends of a non-periodic axis; the halo planes of a slab (a single slab never addresses them)
+        if (!L->periodic[1] && (by == 0 || by == L->nby - 1)) near = true;
+        if (!L->periodic[2] && (bz == 0 || bz == L->nbz - 1)) near = true;
+        if (bx * 8 < HALO + 1 || bx * 8 + 7 >= L->nx + HALO - 1) near = true;
+        for (int x = bx * 8; x < std::min(NX, bx * 8 + 8) && !near; x++)
+          for (int y = by * 8; y < std::min(ny, by * 8 + 8) && !near; y++) {
+            const uint8_t *row = L->hmask.data() + (size_t)x * L->xs + (size_t)y * nz;
+            for (int z = bz * 8; z < std::min(nz, bz * 8 + 8); z++) if (row[z] != 0) { near = true; break; }
+          }
+        flag[((size_t)bx * L->nby + by) * L->nbz + bz] = near ? 1 : 0;
+      }
+  if (!L->wallbrick) HC_HIP(hipMalloc((void **)&L->wallbrick, flag.size()));
+  HC_HIP(hipMemcpy(L->wallbrick, flag.data(), flag.size(), hipMemcpyHostToDevice));
+  return HC_OK;
+}
+
 int launch_collide(hc_lattice *L, int x_begin, int nplanes) {
   if (nplanes <= 0) return HC_OK;
   LatArgs a = make_args(L);
@@ -503,7 +527,9 @@ int hcl_create(hc_lattice **out, int nx, int ny, int nz, const int periodic[3], 
   }
   L->hmask.assign(L->npad, 0);   // device numbering; hcl_set_mask marks the padding
   L->row_z0 = L->row_cum = L->blk_row = nullptr;
+  L->wallbrick = nullptr; L->nbx = (nx + 2 * HALO + 7) / 8; L->nby = (ny + 7) / 8; L->nbz = (nz + 7) / 8;
   { int rc = rebuild_active_map(L); if (rc != HC_OK) return rc; }
+  { int rc = rebuild_wall_bricks(L); if (rc != HC_OK) return rc; }
   HC_HIP(hipStreamSynchronize(hc::stream()));
   *out = L;
   return HC_OK;
@@ -520,6 +546,7 @@ int hcl_destroy(hc_lattice *L) {
   if (L->row_z0) hipFree(L->row_z0);
   if (L->row_cum) hipFree(L->row_cum);
   if (L->blk_row) hipFree(L->blk_row);
+  if (L->wallbrick) hipFree(L->wallbrick);
   delete L;
   return HC_OK;
 }
@@ -587,6 +614,7 @@ int hcl_set_mask(hc_lattice *L, const uint8_t *mask_with_halo) {
     L->hmask.swap(cls);
   }
   { int rc = rebuild_active_map(L); if (rc != HC_OK) return rc; }
+  { int rc = rebuild_wall_bricks(L); if (rc != HC_OK) return rc; }
   HC_HIP(hipMemcpyAsync(L->mask, L->hmask.data(), L->npad, hipMemcpyHostToDevice, hc::stream()));
   HC_HIP(hipStreamSynchronize(hc::stream()));
   return HC_OK;

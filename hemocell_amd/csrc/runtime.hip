@@ -1,6 +1,7 @@
 // Runtime plumbing of libhemocell_amd.so: error string, device selection,
 // stream, per-kernel hipEvent profiling.
 #include "common.h"
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 

@@ -317,8 +317,8 @@ int g_slab_overlap = 1;
 
 // one HemoCell::iterate on this slab.  more: another iteration follows in the same call, so the next spread may run beside
 // this collide (never across the end of a call: the caller may edit vertex forces in between).
-int step(Slab *S, long it, int k_p, int force_limit, bool more) {
-  hc_lattice *L = S->L; hc_cells *C = S->C;
+int step(Slab *S, hc_cells *C, long it, int k_p, int force_limit, bool more) {
+  hc_lattice *L = S->L;   // C: null for a fluid-only call (lattice->collideAndStream() of a driver's warm-up loop), whatever is bound
   const bool cells = C != nullptr && C->ntypes > 0;
   const bool particle_step = cells && it % k_p == 0;
   const bool overlap = g_slab_overlap != 0 && L->nx >= 4;
@@ -392,7 +392,7 @@ int run(hc_lattice *L, hc_cells *C, long *iter, int n, int k_p, int force_limit)
   const double t0 = wall_s();
   long it = iter ? *iter : 0;
   for (int s = 0; s < n; s++, it++) {
-    rc = step(S, it, k_p, force_limit, s + 1 < n);
+    rc = step(S, C, it, k_p, force_limit, s + 1 < n);
     if (rc != HC_OK) return rc;
     if (iter) *iter = it + 1;
   }

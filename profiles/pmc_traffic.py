@@ -5,7 +5,9 @@ counter values are KiB per dispatch).  gfx950 correction as prescribed in MI355X
 calibrated in profiles/r01_pmc_collide_traffic.md: FETCH_SIZE reports half of the bytes of a streamed read (x2),
 WRITE_SIZE is exact."""
 import csv
+import hashlib
 import json
+import os
 import sys
 
 NODES = 256 ** 3
@@ -33,6 +35,9 @@ def main():
         "kernel": "collide_stream_kernel",
         "workload": "pipe 256x256x256, R=127, 1937 RBC (bench.py default)",
         "nodes": NODES,
+        # build of the kernel these counters belong to (= hc_build_tag(): SHA-256 of csrc/lattice.hip, 16 hex digits);
+        # bench.py quotes the figure only next to timings of the same build
+        "kernel_tag": hashlib.sha256(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "hemocell_amd", "csrc", "lattice.hip"), "rb").read()).hexdigest()[:16],
         "FETCH_SIZE_KiB_avg": fetch[key], "WRITE_SIZE_KiB_avg": write[key],
         "correction": "gfx950: FETCH_SIZE counts 1/2 of streamed read bytes (MI355X_MICROARCH.md, HBM section) -> x2; WRITE_SIZE exact; "
                       "calibrated on the all-fluid box (177/176 B per node, profiles/r01_pmc_collide_traffic.md)",

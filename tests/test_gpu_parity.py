@@ -773,6 +773,51 @@ def test_full_size_properties_config3(gpu):
     L.destroy()
 
 
+def test_full_size_properties_north_star_target_512_pipe(gpu):
+    """the north_star target configuration (512^3 D3Q19 pipe, 10 % hematocrit, one GPU: 134 M nodes, ~16 000 RBC, 10.3 M
+    vertices -- what `bench.py --nx 512 --ny 512 --nz 512` times) through size-independent properties: mass conserved to
+    round-off, no cell lost, no particle deleted, volumes and areas at their equilibrium values, the spread force field sums
+    to the vertex forces, the cells move down the pipe with the flow"""
+    from hemocell_amd.packing import pack_pipe_rbc
+    nx = ny = nz = 512
+    P = gpu.base_parameters()
+    mask, R = gpu.pipe_mask(nx, ny, nz)
+    L = gpu.Lattice(nx, ny, nz, (1, 0, 0), 1.0 / P.tau)
+    L.defineBounceBack(mask); L.latticeEquilibrium()
+    n_fluid = int((mask == 0).sum())
+    del mask
+    h = gpu.HemoCell(L, P)
+    Tr = gpu.CellType.rbc(P)
+    h.cellfields.addCellType(Tr, 20); h.setParticleVelocityUpdateTimeScaleSeparation(5)
+    centres, angles = pack_pipe_rbc(nx, ny, nz, 0.10)
+    n_rbc = sum(h.cellfields.addCell(0, c, a, cell_id=i) for i, (c, a) in enumerate(zip(centres, angles)))
+    assert n_rbc == len(centres) and 15000 < n_rbc < 17500
+    cf = h.cellfields
+    cf.applyConstitutiveModel(0, True)
+    L.setExternalVector((2e-6, 0, 0))
+    ms = L.fluid_stats(2); m0 = ms[2] * ms[3]
+    cf.spreadParticleForce(True)
+    Fmn, Fmx, Favg, Fn = L.fluid_stats(1)
+    assert Fn == n_fluid and Fmn > 0
+    # Sum(spread) = Sum(vertex forces): the membrane forces of free cells sum to zero, so the field's mean stays the body force
+    f = cf.forces
+    assert np.abs(f.sum(axis=0)).max() < 1e-9 * np.abs(f).sum()
+    del f
+    gpu.capi.check(gpu.capi.lib().hcl_zero_ibm_force(L.ptr))
+    h.iterate(40)
+    ms = L.fluid_stats(2); m1 = ms[2] * ms[3]
+    assert abs(m1 - m0) <= 4e-9                                # sum over 134 M nodes x 19 populations
+    assert cf.counts() == (n_rbc * 642, n_rbc, 0) and cf.deletion_counts() == (0, 0, 0, 0)
+    info = cf.cell_info(0); tab = Tr.tables()
+    assert np.isfinite(info["volume"]).all()
+    assert np.abs(info["volume"] / tab["volume_eq"] - 1).max() < 0.01
+    assert np.abs(info["area"] / (tab["area_mean_eq"] * Tr.nt) - 1).max() < 0.02
+    vmn, vmx, vavg, vn = cf.vertex_stats(1)
+    assert vn == n_rbc * 642 and np.isfinite(vmx) and 0 < vmx < 1e-2
+    assert cf.velocities[:, 0].mean() > 0
+    L.destroy()
+
+
 def test_error_behaviour_of_the_c_abi(gpu):
     """every entry point returns a status and leaves a message in hc_last_error(); nothing is thrown across the ABI and
     nothing falls back silently ('Error behaviour')"""

@@ -332,7 +332,7 @@ int hcp_destroy(hc_cells *C) {
   if (C->ntag_ev) hipEventDestroy(C->ntag_ev);
   if (C->d_bflag) hipFree(C->d_bflag);
   for (int k = 0; k < 2; k++) { if (C->h_iscratch[k]) hipHostFree(C->h_iscratch[k]); if (C->iscratch_ev[k]) hipEventDestroy(C->iscratch_ev[k]); }
-  for (int t = 0; t < 8; t++) { if (C->d_ext[t]) hipFree(C->d_ext[t]); if (C->h_ext[t]) hipHostFree(C->h_ext[t]); if (C->ext_done[t]) hipEventDestroy(C->ext_done[t]); }
+  for (int t = 0; t < 8; t++) { if (C->h_ext[t]) hipHostFree(C->h_ext[t]); if (C->ext_done[t]) hipEventDestroy(C->ext_done[t]); }   // d_ext is the device view of h_ext
   if (C->d_stat) hipFree(C->d_stat);
   if (C->h_stat) hipHostFree(C->h_stat);
   if (C->d_info) hipFree(C->d_info);

@@ -11,6 +11,7 @@ namespace hc {
 void set_error(const std::string &msg);
 int hip_fail(hipError_t e, const char *what, const char *file, int line);
 hipStream_t stream();
+hipStream_t comm_stream();   // third stream: the transfers of slab runs
 // fork-join onto the library's side stream: fork() makes the side stream wait for everything enqueued so far,
 // route(1) sends the following launches there, route(0) back, join() makes the main stream wait for them
 int fork();

@@ -11,6 +11,7 @@ static thread_local std::string g_error;
 static hipStream_t g_own_stream = nullptr;
 static hipStream_t g_stream = nullptr;       // main stream (own, or the caller's through hc_set_stream)
 static hipStream_t g_side = nullptr;         // side stream of fork / join
+static hipStream_t g_comm = nullptr;         // transfers of slab runs (data plane): a message must not hold up the side stream's kernels
 static hipEvent_t g_fork_ev = nullptr, g_join_ev = nullptr;
 static bool g_on_side = false, g_forked = false;
 static bool g_initialised = false;
@@ -27,6 +28,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
   return HC_ERR_HIP;
 }
 hipStream_t stream() { return g_on_side ? g_side : g_stream; }
+hipStream_t comm_stream() { return g_comm; }
 int fork() {
   HC_HIP(hipEventRecord(g_fork_ev, g_stream));
   HC_HIP(hipStreamWaitEvent(g_side, g_fork_ev, 0));
@@ -118,6 +120,7 @@ int hc_init(int device) {
     int lo = 0, hi = 0;
     HC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     HC_HIP(hipStreamCreateWithPriority(&hc::g_side, hipStreamNonBlocking, hi));
+    HC_HIP(hipStreamCreateWithPriority(&hc::g_comm, hipStreamNonBlocking, hi));
     HC_HIP(hipEventCreateWithFlags(&hc::g_fork_ev, hipEventDisableTiming));
     HC_HIP(hipEventCreateWithFlags(&hc::g_join_ev, hipEventDisableTiming));
   }
@@ -133,6 +136,7 @@ int hc_set_stream(void *hip_stream) {
 int hc_synchronize(void) {
   HC_HIP(hipStreamSynchronize(hc::g_stream));
   if (hc::g_side) HC_HIP(hipStreamSynchronize(hc::g_side));
+  if (hc::g_comm) HC_HIP(hipStreamSynchronize(hc::g_comm));
   return HC_OK;
 }
 

@@ -18,8 +18,10 @@
 //
 // Streams: the main stream never waits for a transfer.  It collides the planes that read no halo data; the side stream
 // (hc::fork / route / join) unpacks the faces that arrived, collides the planes next to the faces, packs what those
-// planes just produced and hands it to the data plane, then runs advance, mechanics and the next spread (between velocity
-// updates) or the id headers of the envelope synchronisation (at a velocity update).
+// planes just produced, then runs advance, mechanics and the next spread (between velocity updates).  Every transfer runs
+// on a third stream (hc::comm_stream) between two events -- "packed" on the packing stream, "arrived" for whoever unpacks -- so
+// that a message in flight holds up no kernel: with the transfers on the side stream itself a 2.6 MB face message (0.7 ms
+// as an RCCL send-to-self, rocprofv3 timeline profiles/r02_c_*) kept advance and spread waiting until the collide was over.
 #include "cells.h"
 #include "comm.h"
 
@@ -44,7 +46,7 @@ struct Slab {
   bool planned = false;                      // the cell extents for the coming envelope sync are on their way to the host
   // envelope synchronisation: id headers [side][type][MAX_HDR] (pinned staging, device send / receive, pinned landing)
   long *h_hdr_s = nullptr, *h_hdr_r = nullptr, *d_hdr_s = nullptr, *d_hdr_r = nullptr; int hdr_types = 0;
-  hipEvent_t hdr_ev = nullptr, rec_ready = nullptr, rec_done = nullptr;
+  hipEvent_t hdr_ev = nullptr, rec_ready = nullptr, rec_done = nullptr, halo_packed = nullptr, halo_arrived = nullptr;
   double *d_rec_s[2] = {nullptr, nullptr}, *d_rec_r[2] = {nullptr, nullptr}; size_t rec_cap_s[2] = {0, 0}, rec_cap_r[2] = {0, 0};
   double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
@@ -67,6 +69,8 @@ int make_slab(hc_lattice *L, hc_cells *C, Slab **out) {
     HC_HIP(hipEventCreateWithFlags(&S->hdr_ev, hipEventDisableTiming));
     HC_HIP(hipEventCreateWithFlags(&S->rec_ready, hipEventDisableTiming));
     HC_HIP(hipEventCreateWithFlags(&S->rec_done, hipEventDisableTiming));
+    HC_HIP(hipEventCreateWithFlags(&S->halo_packed, hipEventDisableTiming));
+    HC_HIP(hipEventCreateWithFlags(&S->halo_arrived, hipEventDisableTiming));
     g_slabs[L] = S;
   }
   if (C) {
@@ -91,8 +95,11 @@ int make_slab(hc_lattice *L, hc_cells *C, Slab **out) {
 }
 
 // ---------------------------------------------------------------------------- lattice faces
-// pack my faces (from the buffer the collide in progress is writing when next != 0) and hand them to the data plane on the
-// stream in use; halo_finish() later unpacks what arrived, on the stream in use then
+// the stream transfers run on: the library's third stream, or -- strictly-one-stream mode -- the stream in use
+hipStream_t transfer_stream();
+
+// pack my faces (from the buffer the collide in progress is writing when next != 0) on the stream in use and hand them to the
+// data plane on the transfer stream; halo_finish() later unpacks what arrived, on the stream in use then
 int halo_begin(Slab *S, int width, int next) {
   hc_lattice *L = S->L;
   int lo, hi; hcm::neighbours(periodic_x(L), lo, hi);
@@ -100,9 +107,16 @@ int halo_begin(Slab *S, int width, int next) {
   int rc;
   if (lo >= 0) { rc = next ? hcl_halo_pack_next(L, 0, width, S->hs[w][0]) : hcl_halo_pack(L, 0, width, S->hs[w][0]); if (rc != HC_OK) return rc; }
   if (hi >= 0) { rc = next ? hcl_halo_pack_next(L, 1, width, S->hs[w][1]) : hcl_halo_pack(L, 1, width, S->hs[w][1]); if (rc != HC_OK) return rc; }
+  const hipStream_t X = transfer_stream();
+  if (X != hc::stream()) {
+    // the unpack of the previous message precedes this pack in the packing stream, so the receive buffers are free again
+    HC_HIP(hipEventRecord(S->halo_packed, hc::stream()));
+    HC_HIP(hipStreamWaitEvent(X, S->halo_packed, 0));
+  }
   const size_t bytes = hcl_halo_doubles(L, width) * sizeof(double);
-  rc = hcm::exchange(hc::stream(), periodic_x(L), S->hs[w][0], bytes, S->hs[w][1], bytes, S->hr[w][0], bytes, S->hr[w][1], bytes);
+  rc = hcm::exchange(X, periodic_x(L), S->hs[w][0], bytes, S->hs[w][1], bytes, S->hr[w][0], bytes, S->hr[w][1], bytes);
   if (rc != HC_OK) return rc;
+  if (X != hc::stream()) HC_HIP(hipEventRecord(S->halo_arrived, X));
   S->pending_width = width;
   return HC_OK;
 }
@@ -113,6 +127,7 @@ int halo_finish(Slab *S) {
   int lo, hi; hcm::neighbours(periodic_x(L), lo, hi);
   const int width = S->pending_width, w = width - 1;
   int rc;
+  if (transfer_stream() != hc::stream()) HC_HIP(hipStreamWaitEvent(hc::stream(), S->halo_arrived, 0));
   if (lo >= 0) { rc = hcl_halo_unpack(L, 0, width, S->hr[w][0]); if (rc != HC_OK) return rc; }
   if (hi >= 0) { rc = hcl_halo_unpack(L, 1, width, S->hr[w][1]); if (rc != HC_OK) return rc; }
   S->pending_width = 0;
@@ -143,8 +158,8 @@ int plan_cells(Slab *S) {
   return HC_OK;
 }
 
-// first part, needs positions only: which cells cross which face, which were deleted; the id headers leave on the stream
-// in use and land in pinned memory behind an event
+// first part, needs positions only: which cells cross which face, which were deleted; the id headers leave on the transfer
+// stream (ahead of the wide face message of the same step) and land in pinned memory behind an event
 int sync_begin(Slab *S, std::vector<Plan> &plans) {
   hc_cells *C = S->C; hc_lattice *L = S->L;
   int lo, hi; hcm::neighbours(periodic_x(L), lo, hi);
@@ -179,12 +194,13 @@ int sync_begin(Slab *S, std::vector<Plan> &plans) {
   }
   S->stats[6] += wall_s() - t_wait;
   const size_t side_bytes = (size_t)C->ntypes * MAX_HDR * sizeof(long);
-  HC_HIP(hipMemcpyAsync(S->d_hdr_s, S->h_hdr_s, 2 * side_bytes, hipMemcpyHostToDevice, hc::stream()));
-  int rc = hcm::exchange(hc::stream(), periodic_x(L), S->d_hdr_s, side_bytes, (char *)S->d_hdr_s + side_bytes, side_bytes, S->d_hdr_r, side_bytes,
+  const hipStream_t X = transfer_stream();   // the headers depend on host data only: nothing to wait for
+  HC_HIP(hipMemcpyAsync(S->d_hdr_s, S->h_hdr_s, 2 * side_bytes, hipMemcpyHostToDevice, X));
+  int rc = hcm::exchange(X, periodic_x(L), S->d_hdr_s, side_bytes, (char *)S->d_hdr_s + side_bytes, side_bytes, S->d_hdr_r, side_bytes,
                          (char *)S->d_hdr_r + side_bytes, side_bytes);
   if (rc != HC_OK) return rc;
-  HC_HIP(hipMemcpyAsync(S->h_hdr_r, S->d_hdr_r, 2 * side_bytes, hipMemcpyDeviceToHost, hc::stream()));
-  HC_HIP(hipEventRecord(S->hdr_ev, hc::stream()));
+  HC_HIP(hipMemcpyAsync(S->h_hdr_r, S->d_hdr_r, 2 * side_bytes, hipMemcpyDeviceToHost, X));
+  HC_HIP(hipEventRecord(S->hdr_ev, X));
   return HC_OK;
 }
 
@@ -314,6 +330,7 @@ int repulsion_at(hc_cells *C, long it) {
 }
 
 int g_slab_overlap = 1;
+hipStream_t transfer_stream() { return g_slab_overlap ? hc::comm_stream() : hc::stream(); }
 
 // one HemoCell::iterate on this slab.  more: another iteration follows in the same call, so the next spread may run beside
 // this collide (never across the end of a call: the caller may edit vertex forces in between).
@@ -341,6 +358,7 @@ int step(Slab *S, hc_cells *C, long it, int k_p, int force_limit, bool more) {
     }
     if (cells) { TRY(hcp_advance(C, 0)); TRY(hcp_mechanics(C, it, 0)); }         // :342, :345
   } else if (particle_step) {
+    TRY(sync_begin(S, plans));                     // id headers first (the host waits for the extents taken after the last advance): they are tiny
     TRY(hc::fork());
     hc::route(1);
     TRY(halo_make_fresh(S, 1));                    // the neighbours' faces (on their way since the previous step)
@@ -350,13 +368,11 @@ int step(Slab *S, hc_cells *C, long it, int k_p, int force_limit, bool more) {
     TRY(hcl_collide_stream_part(L, 3));            // main stream: planes 2 .. nx-3
     hcl_step_end(L);
     hc::route(1);
-    TRY(sync_begin(S, plans));                     // the host waits for the extents in there, the interior collide already queued
     TRY(halo_finish(S));                           // wide faces of the neighbours -> halo planes of the new state
-    const hipStream_t side = hc::stream();
     TRY(hc::join());
-    TRY(sync_records(S, plans, side));             // crossing cells interpolated first; their records leave on the side stream
+    TRY(sync_records(S, plans, transfer_stream()));   // crossing cells interpolated first; their records leave on the transfer stream
     TRY(hcp_interpolate(C));                       // :327-332, all cells, while the records travel
-    TRY(sync_merge(S, plans, side));
+    TRY(sync_merge(S, plans, transfer_stream()));
     TRY(hcp_advance(C, 0));                        // :342
     TRY(hcp_mechanics(C, it, 0));                  // :345
     S->halo_fresh = true;                          // width 2 covers what the next collide reads
@@ -422,7 +438,7 @@ void lattice_destroyed(hc_lattice *L) {
   if (S->d_hdr_s) hipFree(S->d_hdr_s);
   if (S->d_hdr_r) hipFree(S->d_hdr_r);
   for (int side = 0; side < 2; side++) { if (S->d_rec_s[side]) hipFree(S->d_rec_s[side]); if (S->d_rec_r[side]) hipFree(S->d_rec_r[side]); }
-  for (hipEvent_t e : {S->hdr_ev, S->rec_ready, S->rec_done}) if (e) hipEventDestroy(e);
+  for (hipEvent_t e : {S->hdr_ev, S->rec_ready, S->rec_done, S->halo_packed, S->halo_arrived}) if (e) hipEventDestroy(e);
   delete S;
   g_slabs.erase(it);
 }

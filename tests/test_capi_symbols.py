@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     src = open(os.path.join(ROOT, "include", "hemocell_amd.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"^(?:const\s+char\s*\*\s*|int\s+|size_t\s+|double\s+)(hc[a-z_]*)\s*\(", src, flags=re.M)
+    names = re.findall(r"^(?:const\s+char\s*\*\s*|int\s+|size_t\s+|double\s+)(hc[a-z_0-9]*)\s*\(", src, flags=re.M)
     return sorted(set(names))
 
 

@@ -57,6 +57,7 @@ int main(int argc, char *argv[]) {
   if (hemocell.iter == 0)
     for (plint i = 0; i < (*cfg)["parameters"]["warmup"].read<plint>(); ++i) hemocell.lattice->collideAndStream();
 
+  if (std::getenv("HEMOCELL_PRINT_KERNEL_TIMES")) { hemocell.flush(); hemo::global.statistics.start(); }
   const unsigned tcheckpoint = (*cfg)["sim"]["tcheckpoint"].read<unsigned int>();
   const unsigned tmax = (*cfg)["sim"]["tmax"].read<unsigned int>(), tmeas = (*cfg)["sim"]["tmeas"].read<unsigned int>();
   while (hemocell.iter < tmax) {
@@ -71,6 +72,10 @@ int main(int argc, char *argv[]) {
                   (param::u_lbm_max * 0.5) / finfo.avg, pinfo.avg * param::df * 1.0e12);
     }
     if (hemocell.iter % tcheckpoint == 0) hemocell.saveCheckPoint();
+  }
+  if (std::getenv("HEMOCELL_PRINT_KERNEL_TIMES")) {   // the library's hipEvent timers (what bench.py reports as kernel_ms), for a like-for-like comparison
+    const char *names[] = {"collide_stream_alone", "collide_stream_beside", "ibm_spread", "ibm_interpolate", "advance", "mechanics"};
+    for (const char *k : names) { double ms = 0; long n = 0; hc_profile_read(k, &ms, &n); std::printf("KERNEL %s %.4f ms x %ld\n", k, n ? ms / n : 0.0, n); }
   }
   hemocell.writeOutput();   // <out>/hdf5/<iter>/{RBC,PLT,Fluid}.<iter>.p.0.h5 + <out>/csv
   return 0;

@@ -45,19 +45,32 @@ def main():
         f.write("0\n")
     for name in ("RBC.xml", "PLT.xml"):
         shutil.copy(os.path.join(HERE, name), os.path.join(work, name))
-    times, stats = {}, {}
-    for tmax in (200, 2200):
-        with open(os.path.join(work, "config.xml"), "w") as f:
-            f.write(CONFIG % (N - 2, N, tmax, tmax))
-        shutil.rmtree(os.path.join(work, "tmp_out"), ignore_errors=True)
-        t0 = time.perf_counter()
-        out = subprocess.run([drv, "config.xml"], cwd=work, capture_output=True, text=True, check=True).stdout
-        times[tmax] = time.perf_counter() - t0
-        stats[tmax] = [l for l in out.splitlines() if l.startswith("STAT")][-1]
-    ms = (times[2200] - times[200]) / 2000 * 1e3
-    cells = int(stats[2200].split()[2])
-    print("reference-style driver through the facade, pipe %d^3, %d cells: %.4f ms per iterate() = %.0f MLUPS   [%s]"
-          % (N, cells, ms, N ** 3 / ms / 1e3, stats[2200]))
+    import json
+    # the kernels run a few per cent faster or slower from process to process on one box, so the two ways of driving the
+    # workload are run alternately, twice each, and the collide kernel's own time is printed next to each result
+    for rep in range(2):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "1000", "--warmup", "100"],
+                           cwd=ROOT, capture_output=True, text=True, check=True)
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        k = j["kernel_ms"]
+        print("bench.py (hc_iterate, 1000 iterations per call):              %.4f ms per step    [collide alone %.4f ms, beside %.4f ms]"
+              % (j["ms_per_step"], k["collide_stream_alone"]["ms_total"] / k["collide_stream_alone"]["launches"],
+                 k["collide_stream_beside"]["ms_total"] / max(k["collide_stream_beside"]["launches"], 1)))
+        times, stats, kern = {}, {}, {}
+        for tmax in (200, 2200):
+            with open(os.path.join(work, "config.xml"), "w") as f:
+                f.write(CONFIG % (N - 2, N, tmax, tmax))
+            shutil.rmtree(os.path.join(work, "tmp_out"), ignore_errors=True)
+            t0 = time.perf_counter()
+            out = subprocess.run([drv, "config.xml"], cwd=work, capture_output=True, text=True, check=True,
+                                 env=dict(os.environ, HEMOCELL_PRINT_KERNEL_TIMES="1")).stdout
+            times[tmax] = time.perf_counter() - t0
+            stats[tmax] = [l for l in out.splitlines() if l.startswith("STAT")][-1]
+            kern[tmax] = {l.split()[1]: float(l.split()[2]) for l in out.splitlines() if l.startswith("KERNEL")}
+        ms = (times[2200] - times[200]) / 2000 * 1e3
+        cells = int(stats[2200].split()[2])
+        print("reference-style driver through the facade, one iterate() per step: %.4f ms per iterate() [collide alone %.4f ms, beside %.4f ms]   pipe %d^3, %d cells [%s]"
+              % (ms, kern[2200].get("collide_stream_alone", 0), kern[2200].get("collide_stream_beside", 0), N, cells, stats[2200]))
 
 
 if __name__ == "__main__":

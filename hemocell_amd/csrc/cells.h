@@ -50,6 +50,7 @@ struct hc_cells {
   int *d_tag = nullptr;          // [tag_cap] all types, slot order
   long tag_cap = 0;
   unsigned char *d_vdead = nullptr;   // [cap]
+  int *h_ntag_dev = nullptr;     // device view of h_ntag
   int *h_ntag = nullptr;         // pinned host copy of the counters {cells gone and not yet compacted, cells made incomplete}
   int *d_ntag = nullptr;         // device counters [2]
   hipEvent_t ntag_ev = nullptr;  // completion of an asynchronous counter read (hc_iterate polls it, never waits)

@@ -39,6 +39,8 @@ __global__ __launch_bounds__(256) void advance_kernel(LatView v, long n, double 
   }
 }
 
+// the counters go to pinned host memory by a one-thread kernel: a copy operation in the stream would hold the next kernel back
+__global__ void publish_counters_kernel(const int *counters, int *host_view) { for (int k = 0; k < 3; k++) host_view[k] = counters[k]; }
 __global__ void sub_counters_kernel(int *counters, int a, int b, int c) { atomicSub(&counters[0], a); atomicSub(&counters[1], b); atomicSub(&counters[2], c); }
 
 // deleteIncompleteCells (core/hemoCellParticleField.cpp:512-553): every incomplete cell goes
@@ -314,7 +316,8 @@ int hcp_create(hc_cells **out, hc_lattice *L, const hc_params *P) {
   hc_cells *C = new hc_cells();
   C->L = L; C->P = *P;
   L->ibm = 1;
-  HC_HIP(hipHostMalloc((void **)&C->h_ntag, 4 * sizeof(int), hipHostMallocDefault));
+  HC_HIP(hipHostMalloc((void **)&C->h_ntag, 4 * sizeof(int), hipHostMallocMapped));
+  HC_HIP(hipHostGetDevicePointer((void **)&C->h_ntag_dev, C->h_ntag, 0));
   for (int k = 0; k < 4; k++) C->h_ntag[k] = 0;
   HC_HIP(hipMalloc((void **)&C->d_ntag, 4 * sizeof(int)));
   HC_HIP(hipMemset(C->d_ntag, 0, 4 * sizeof(int)));
@@ -664,7 +667,8 @@ int settle(hc_cells *C) {
   if (C->host_dirty || !C->d_ntag) return HC_OK;      // the host staging is authoritative: nothing ran on the device since
   if (!C->maybe_tagged && !C->ntag_pending) return HC_OK;
   C->maybe_tagged = false; C->ntag_pending = false;
-  HC_HIP(hipMemcpyAsync(C->h_ntag, C->d_ntag, 4 * sizeof(int), hipMemcpyDeviceToHost, hc::stream()));
+  hipLaunchKernelGGL(publish_counters_kernel, dim3(1), dim3(1), 0, hc::stream(), (const int *)C->d_ntag, C->h_ntag_dev);
+  HC_HIP(hipGetLastError());
   HC_HIP(hipStreamSynchronize(hc::stream()));
   return apply_counters(C);
 }
@@ -679,7 +683,8 @@ static int poll_deletions(hc_cells *C, bool start_next) {
     int rc = apply_counters(C); if (rc != HC_OK) return rc;
   }
   if (start_next && C->maybe_tagged) {
-    HC_HIP(hipMemcpyAsync(C->h_ntag, C->d_ntag, 4 * sizeof(int), hipMemcpyDeviceToHost, hc::stream()));
+    hipLaunchKernelGGL(publish_counters_kernel, dim3(1), dim3(1), 0, hc::stream(), (const int *)C->d_ntag, C->h_ntag_dev);
+    HC_HIP(hipGetLastError());
     HC_HIP(hipEventRecord(C->ntag_ev, hc::stream()));
     C->ntag_pending = true; C->maybe_tagged = false;
   }

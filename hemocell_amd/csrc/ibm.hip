@@ -46,6 +46,10 @@ struct PopView {
 };
 
 __device__ __forceinline__ void node_velocity(const LatView &v, const PopView &pv, int lx, int ly, int lz, long node, double u[3]) {
+  // A node on the OUTER halo plane of a slab would pull from beyond the allocation.  Only particles whose nearest node lies
+  // outside the slab have such a node in their stencil, and their interpolated velocity is never used (the owner's record
+  // replaces it, "a local particle wins"), so the value does not matter -- the access must not happen.
+  if (v.halo_x && (lx <= -HALO || lx >= v.nx + HALO - 1)) { u[0] = u[1] = u[2] = 0.0; return; }
   // gather S(node,q) = P(node - c_q, q) with the same wrap rules as the collide kernel
   long xm = -(long)v.plane, xp = (long)v.plane;
   if (v.wrap_x) { if (lx == 0) xm = (long)(v.nx - 1) * v.plane; if (lx == v.nx - 1) xp = -(long)(v.nx - 1) * v.plane; }

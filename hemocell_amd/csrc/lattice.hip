@@ -753,12 +753,14 @@ int hcl_fluid_stats(hc_lattice *L, int what, double out[3], long *n_nodes) {
 
 size_t hcl_halo_doubles(const hc_lattice *L, int width) {
   if (!L) return 0;
-  return (size_t)(width == 1 ? 5 : HC_Q + 5) * L->plane;
+  return (size_t)(width == 1 ? 5 : 14 + 5) * L->plane;
 }
 
 // width 1 (every step): the 5 populations that cross the face.  width 2 (before interpolation): everything the
-// neighbour needs to evaluate node velocities on its first halo plane -- all 19 populations of the face plane plus,
-// from the plane behind it, the 5 that stream onto that halo plane.
+// neighbour needs to evaluate node velocities on its first halo plane.  S(x, i) = P(x - c_i, i) there pulls the 9 populations
+// with c_x = 0 from the face plane itself, the 5 moving towards the neighbour from the plane behind it, and the 5 moving
+// away from the neighbour out of the neighbour's own first plane; the neighbour's next collide pulls the 5 moving towards
+// it from the face plane.  So 14 populations of the face plane and 5 of the plane behind travel: 19 planes, not 24.
 static int halo_copy(hc_lattice *L, int side, int width, double *buf, int to_buf, int next = 0) {
   HC_REQUIRE(L && buf, "hcl_halo: null pointer");
   HC_REQUIRE((side == 0 || side == 1) && (width == 1 || width == 2), "hcl_halo: side must be 0/1 and width 1/2");
@@ -776,7 +778,12 @@ static int halo_copy(hc_lattice *L, int side, int width, double *buf, int to_buf
   if (width == 1) {
     for (int k = 0; k < 5; k++) { h.pop[h.n] = moving[k]; h.xp[h.n] = near; h.n++; }
   } else {
-    for (int q = 0; q < HC_Q; q++) { h.pop[h.n] = q; h.xp[h.n] = near; h.n++; }
+    static const int cx[HC_Q] = HC_CX;
+    for (int q = 0; q < HC_Q; q++) {
+      bool towards = false;
+      for (int k = 0; k < 5; k++) towards = towards || moving[k] == q;
+      if (cx[q] == 0 || towards) { h.pop[h.n] = q; h.xp[h.n] = near; h.n++; }
+    }
     for (int k = 0; k < 5; k++) { h.pop[h.n] = moving[k]; h.xp[h.n] = far; h.n++; }
   }
   hipLaunchKernelGGL(halo_copy_kernel, dim3((unsigned)((L->plane + 255) / 256), (unsigned)h.n, 1), dim3(256), 0, hc::stream(), h);

@@ -155,9 +155,9 @@ int hcl_fluid_stats(hc_lattice *L, int what, double out[3], long *n_nodes);
 int hcl_download_ibm_force(hc_lattice *L, double *F);
 int hcl_zero_ibm_force(hc_lattice *L);
 /* halo exchange (Palabos duplicateOverlaps(staticVariables), core/hemoCell.cpp:142).  width = 1 (5
- * populations per face, enough for one collide-stream) or 2 (needed before an IBM interpolation: the 19
- * populations of the face plane and, from the plane behind it, the 5 that stream onto the neighbour's first
- * halo plane).  side 0 = low-x face, 1 = high-x face.  Buffers are DEVICE pointers of
+ * populations per face, enough for one collide-stream) or 2 (needed before an IBM interpolation: the 14
+ * populations of the face plane that do not move away from the neighbour and, from the plane behind it, the 5
+ * that stream onto the neighbour's first halo plane).  side 0 = low-x face, 1 = high-x face.  Buffers are DEVICE pointers of
  * hcl_halo_doubles(L,width) doubles each. */
 size_t hcl_halo_doubles(const hc_lattice *L, int width);
 int hcl_halo_pack(hc_lattice *L, int side, int width, double *dev_buf);

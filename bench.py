@@ -229,6 +229,17 @@ def main():
         m2, n2 = C.c_double(), C.c_long()
         host.check(lib.hc_profile_read(k.encode(), C.byref(m2), C.byref(n2)))
         prof[k] = {"ms_total": m2.value, "launches": n2.value}
+    # After the timed region: the dominant kernel with the GPU to itself (inside the timed region four launches of five share
+    # it with advance and the next spread on the side stream)
+    alone_ms = None
+    if world == 1:
+        lib.hc_profile_reset(); lib.hc_profile_enable(1)
+        runner.lattice.collideAndStream(10)
+        host.check(lib.hc_synchronize())
+        m2, n2 = C.c_double(), C.c_long()
+        host.check(lib.hc_profile_read(b"collide_stream", C.byref(m2), C.byref(n2)))
+        lib.hc_profile_enable(0)
+        alone_ms = m2.value / max(n2.value, 1)
 
     if rank == 0:
         nodes = nxg * args.ny * args.nz
@@ -237,8 +248,11 @@ def main():
         # dominant kernel: collide_stream_kernel.  Per step and rank it processes the nx*ny*nz nodes of the slab
         # (one launch, or an interior + boundary-plane launches when faces are in flight); the hipEvent brackets are on the
         # stream the kernel runs on (hc_profile_*), rank 0's numbers are reported.
-        launch_nodes = args.nx * args.ny * args.nz
-        avg_ms = ms.value / args.steps
+        step_nodes = args.nx * args.ny * args.nz                # nodes one rank's collide launches of ONE iteration cover between them
+        launches_per_step = n.value / float(args.steps)           # 1 on one GPU; 2-3 on a slab (interior planes and face planes apart)
+        launch_nodes = step_nodes / launches_per_step            # algorithmic share of one launch, on average
+        avg_ms = ms.value / max(n.value, 1)                       # average duration of ONE launch (what rocprofv3 --stats averages too)
+        step_ms = ms.value / args.steps                           # the collide launches of one iteration together
         achieved = launch_nodes * bytes_per_node / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM bytes per launch of that kernel from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
         # passes, FETCH doubled per the gfx950 note): measured offline on exactly this workload AND this build of the kernel
@@ -274,22 +288,20 @@ def main():
             # `traffic` (PMC) and `frac_real_traffic` = traffic / time / peak say what the HBM actually delivered.
             "roofline": {"bound": "hbm", "kernel": "collide_stream_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
-                         "frac_real_traffic": (traffic / (avg_ms * 1e-3) / 8.0e12) if (traffic and avg_ms > 0) else None,
-                         "real_traffic_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
+                         # `traffic` is HBM bytes per ITERATION (all collide launches of a step, PMC sum); real rate = traffic / their time
+                         "frac_real_traffic": (traffic / (step_ms * 1e-3) / 8.0e12) if (traffic and step_ms > 0) else None,
+                         "real_traffic_GBps": (traffic / (step_ms * 1e-3) / 1e9) if (traffic and step_ms > 0) else None,
                          # without a PMC figure for this workload: the bytes of the nodes the kernel visits (an upper bound of what moves)
-                         "frac_active_nodes": (active_nodes / world) * bytes_per_node / (avg_ms * 1e-3) / 8.0e12 if avg_ms > 0 else None,
+                         "frac_active_nodes": (active_nodes / world) * bytes_per_node / (step_ms * 1e-3) / 8.0e12 if step_ms > 0 else None,
                          "algorithmic_bytes_per_launch": launch_nodes * bytes_per_node,
                          "bytes_per_node": bytes_per_node, "nodes_per_launch": launch_nodes, "avg_launch_ms": avg_ms,
-                         "launches": n.value, "kernel_build": tag,
+                         "launches": n.value, "launches_per_step": launches_per_step, "collide_ms_per_step": step_ms, "kernel_build": tag,
                          "peak_source": "MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)",
                          "copy_GBps_this_gpu": cbw.value},
             "kernel_ms": prof,
-            # the same kernel over the launches that had the GPU to themselves (velocity-update steps); the others share
-            # it with advance + spread of the next iteration on the side stream, which stretches both
-            "roofline_alone": ({"avg_launch_ms": prof["collide_stream_alone"]["ms_total"] / prof["collide_stream_alone"]["launches"] * (n.value / args.steps),
-                                "launches": prof["collide_stream_alone"]["launches"],
-                                "frac": launch_nodes * bytes_per_node / (prof["collide_stream_alone"]["ms_total"] / prof["collide_stream_alone"]["launches"] * (n.value / args.steps) * 1e-3) / 8.0e12}
-                               if prof["collide_stream_alone"]["launches"] else None),
+            # the same kernel with the GPU to itself (10 launches right after the timed region)
+            "roofline_alone": ({"avg_launch_ms": alone_ms, "launches": 10, "frac": step_nodes * bytes_per_node / (alone_ms * 1e-3) / 8.0e12,
+                                "frac_real_traffic": (traffic / (alone_ms * 1e-3) / 8.0e12) if traffic else None} if alone_ms else None),
             # whole job against the HBM roofline of the whole step: MLUPS x algorithmic bytes per node update over the
             # aggregate 8 TB/s of the GPUs used (north_star: >= 0.60 on the 512^3 pipe at 1 GPU)
             "whole_step_hbm_frac": mlups * 1e6 * bytes_per_node / (8.0e12 * world),

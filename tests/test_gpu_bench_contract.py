@@ -31,7 +31,9 @@ def test_bench_line_small_pipe(gpu):
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in rf, key
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches"] == 20
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches"] == 20 and rf["launches_per_step"] == 1.0
+    assert abs(rf["achieved"] * 1e9 - 64 * 66 * 66 * rf["bytes_per_node"] / (rf["collide_ms_per_step"] * 1e-3)) < 1e-6 * rf["achieved"] * 1e9
+    assert j["roofline_alone"]["launches"] == 10 and j["roofline_alone"]["frac"] > rf["frac"] * 0.8   # the kernel with the GPU to itself, measured after the timed region
     assert rf["copy_GBps_this_gpu"] > 1000 and rf["traffic"] is None and rf["frac_real_traffic"] is None   # the PMC figure belongs to the 256^3 headline workload only
     # the line says what the 353 B/node convention hides: fluid-node-only rate and the share of the box the kernel visits
     assert 0.5 < j["fluid_node_fraction"] < j["active_node_fraction"] < 1.0

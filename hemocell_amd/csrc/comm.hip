@@ -17,6 +17,7 @@
 #include <arpa/inet.h>
 #include <cerrno>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
@@ -320,7 +321,8 @@ extern "C" {
 
 int hc_comm_init(int rank, int world, int local_rank, const char *master_addr, int port, int transport, int init_device) {
   HC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "hc_comm_init: rank must be in [0, world)");
-  HC_REQUIRE(transport == HC_TRANSPORT_NONE || transport == HC_TRANSPORT_RCCL || transport == HC_TRANSPORT_TCP, "hc_comm_init: unknown transport");
+  HC_REQUIRE(transport == HC_TRANSPORT_NONE || transport == HC_TRANSPORT_RCCL || transport == HC_TRANSPORT_TCP || transport == HC_TRANSPORT_AUTO,
+             "hc_comm_init: unknown transport");
   HC_REQUIRE(port > 0 && port + world < 65536, "hc_comm_init: port out of range");
   if (g.inited) return fail("already initialised (one world per process, core/hemoCell.cpp:75-79)");
   if (const char *t = std::getenv("HEMOCELL_COMM_TIMEOUT")) { const double v = std::atof(t); if (v > 0) g.timeout_s = v; }
@@ -330,20 +332,53 @@ int hc_comm_init(int rank, int world, int local_rank, const char *master_addr, i
     if (ndev < 1) return fail("no HIP device");
     rc = hc_init(local_rank % ndev); if (rc != HC_OK) return rc;
   }
+  const bool automatic = transport == HC_TRANSPORT_AUTO;
+  if (automatic) transport = HC_TRANSPORT_RCCL;
   g.rank = rank; g.world = world; g.transport = transport;
   int rc = connect_mesh(master_addr ? master_addr : "127.0.0.1", port);
   if (rc != HC_OK) return rc;
+  g.inited = true;   // the control plane is up: broadcasts and reductions below go over the mesh
   if (transport == HC_TRANSPORT_RCCL) {
-    rc = load_rccl(); if (rc != HC_OK) return rc;
+    // every rank learns whether EVERY rank got its communicator and passed the self-test; they all take the same branch
+    std::string why;
+    double ok = 1.0;
+    if (load_rccl() != HC_OK) { ok = 0.0; why = hc_last_error(); }
     ncclUniqueId id; std::memset(&id, 0, sizeof(id));
-    if (rank == 0) HC_NCCL(g.rccl.GetUniqueId(&id));
-    g.inited = true;   // bcast below goes over the mesh
-    rc = hcm::bcast(&id, sizeof(id), 0);
-    if (rc != HC_OK) { g.inited = false; return rc; }
-    const ncclResult_t r = g.rccl.CommInitRank(&g.comm, world, id, rank);
-    if (r != ncclSuccess) { g.inited = false; return fail(std::string("RCCL: ") + g.rccl.GetErrorString(r) + " in ncclCommInitRank (two ranks on one GPU? use HEMOCELL_TRANSPORT=tcp)"); }
+    if (ok > 0 && rank == 0) { const ncclResult_t r = g.rccl.GetUniqueId(&id); if (r != ncclSuccess) { ok = 0.0; why = std::string("ncclGetUniqueId: ") + g.rccl.GetErrorString(r); } }
+    rc = hcm::allreduce(&ok, 1, 1); if (rc != HC_OK) { g.inited = false; return rc; }
+    if (ok > 0) {
+      rc = hcm::bcast(&id, sizeof(id), 0); if (rc != HC_OK) { g.inited = false; return rc; }
+      const ncclResult_t r = g.rccl.CommInitRank(&g.comm, world, id, rank);
+      if (r != ncclSuccess) { ok = 0.0; g.comm = nullptr; why = std::string("ncclCommInitRank: ") + g.rccl.GetErrorString(r) + " (two ranks on one GPU?)"; }
+      rc = hcm::allreduce(&ok, 1, 1); if (rc != HC_OK) { g.inited = false; return rc; }
+    }
+    if (ok > 0) {   // self-test: one small ring exchange must complete, or the run would hang in its first step instead of failing here
+      char *d = nullptr; hipEvent_t ev = nullptr;
+      hipError_t e = hipMalloc((void **)&d, 4 * 4096);
+      if (e == hipSuccess) e = hipMemset(d, 1, 4 * 4096);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+      if (e != hipSuccess) { ok = 0.0; why = std::string("self-test set-up: ") + hipGetErrorString(e); }
+      if (ok > 0 && hcm::exchange(hc::comm_stream(), true, d, 4096, d + 4096, 4096, d + 2 * 4096, 4096, d + 3 * 4096, 4096) != HC_OK) { ok = 0.0; why = hc_last_error(); }
+      if (ok > 0) {
+        hipEventRecord(ev, hc::comm_stream());
+        const double t0 = now_s();
+        while (hipEventQuery(ev) == hipErrorNotReady) {
+          if (now_s() - t0 > 60.0) { ok = 0.0; why = "the point-to-point self-test did not complete within 60 s"; break; }
+          std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+      }
+      if (ok > 0) { if (ev) hipEventDestroy(ev); if (d) hipFree(d); }   // after a hung transfer the stream still owns them
+      rc = hcm::allreduce(&ok, 1, 1); if (rc != HC_OK) { g.inited = false; return rc; }
+    }
+    if (ok <= 0) {
+      if (g.comm) { g.rccl.CommDestroy(g.comm); g.comm = nullptr; }
+      if (why.empty()) why = "another rank failed to set RCCL up";
+      if (!automatic) { g.inited = false; return fail("RCCL data plane: " + why + " (HEMOCELL_TRANSPORT=tcp stages the messages through the host instead)"); }
+      // automatic choice: say so loudly and stage the messages through the host -- a slower run, not a different result
+      if (rank == 0) std::fprintf(stderr, "(hemocell_amd) RCCL point-to-point is not usable here (%s): the neighbour exchange is staged through pinned host memory and TCP instead\n", why.c_str());
+      g.transport = HC_TRANSPORT_TCP;
+    }
   }
-  g.inited = true;
   return hcm::barrier();
 }
 
@@ -358,10 +393,11 @@ int hc_comm_init_env(void) {
   const int local = env_int({"HEMOCELL_LOCAL_RANK", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID"}, rank);
   const char *addr = std::getenv("MASTER_ADDR");
   const int port = env_int({"HEMOCELL_PORT"}, env_int({"MASTER_PORT"}, 29400) + 1017);
-  int transport = HC_TRANSPORT_RCCL;
+  int transport = HC_TRANSPORT_AUTO;   // RCCL, or -- said loudly -- host staging when RCCL cannot be set up (ranks sharing a GPU)
   if (const char *t = std::getenv("HEMOCELL_TRANSPORT")) {
     if (std::strcmp(t, "tcp") == 0) transport = HC_TRANSPORT_TCP;
-    else if (std::strcmp(t, "rccl") != 0 && *t) { hc::set_error(std::string("hc_comm_init_env: HEMOCELL_TRANSPORT must be rccl or tcp, got ") + t); return HC_ERR_ARG; }
+    else if (std::strcmp(t, "rccl") == 0) transport = HC_TRANSPORT_RCCL;
+    else if (*t) { hc::set_error(std::string("hc_comm_init_env: HEMOCELL_TRANSPORT must be rccl or tcp, got ") + t); return HC_ERR_ARG; }
   }
   return hc_comm_init(rank, world, local, (addr && *addr) ? addr : "127.0.0.1", port, transport, 1);
 }

@@ -16,7 +16,7 @@ import numpy as np
 
 from . import host
 
-TRANSPORT = {"none": 0, "rccl": 1, "tcp": 2}
+TRANSPORT = {"none": 0, "rccl": 1, "tcp": 2, "auto": 3}
 
 
 def comm_init_env():

@@ -80,11 +80,12 @@ int hc_debug_force_plane_padding(int on); /* tests / A-B runs: lattices created 
  *                  on one device), i.e. rehearsals and tests on a one-GPU box.
  * hc_comm_init_env reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (torch.distributed.run's names; also
  * OMPI_COMM_WORLD_RANK / _SIZE / _LOCAL_RANK and PMI_RANK / PMI_SIZE of an mpirun), HEMOCELL_PORT (default MASTER_PORT + 1017)
- * and HEMOCELL_TRANSPORT = rccl (default) | tcp, selects the device LOCAL_RANK modulo the device count (hc_init) and
+ * and HEMOCELL_TRANSPORT = rccl | tcp (unset: HC_TRANSPORT_AUTO), selects the device LOCAL_RANK modulo the device count (hc_init) and
  * connects.  Without those variables it is a one-rank world and does nothing. */
 #define HC_TRANSPORT_NONE 0
 #define HC_TRANSPORT_RCCL 1
 #define HC_TRANSPORT_TCP 2
+#define HC_TRANSPORT_AUTO 3   /* RCCL when every rank can set it up and a ring self-test completes; otherwise TCP, announced on stderr */
 int hc_comm_init_env(void);
 /* explicit form; init_device != 0: also hc_init(local_rank % device count).  transport HC_TRANSPORT_NONE builds the control
  * plane only (host-side use without a GPU: the CPU tests of the mesh). */

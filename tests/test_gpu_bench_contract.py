@@ -50,7 +50,7 @@ def test_bench_line_small_pipe(gpu):
     assert k["collide_stream_beside"]["launches"] > 0 and k["ibm_interpolate"]["launches"] == 4
 
 
-@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+@pytest.mark.parametrize("launcher", ["self", "torchrun", "self-auto"])
 def test_bench_two_ranks_share_the_gpu(gpu, launcher):
     """the N > 1 path of bench.py, rehearsed with two ranks on the one GPU of the test box: started plainly
     (`python bench.py --gpus 2`, which spawns its ranks) and the way the driver starts it (torch.distributed.run, one
@@ -58,14 +58,15 @@ def test_bench_two_ranks_share_the_gpu(gpu, launcher):
     so the data plane is the library's TCP staging here; everything else -- native slab schedule, streams, timing,
     reduction of the result -- is the same code"""
     port = str(29700 + os.getpid() % 200)
-    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nx", "64", "--ny", "66", "--nz", "66", "--steps", "20", "--warmup", "5",
-            "--transport", "tcp"]
-    if launcher == "self":
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nx", "64", "--ny", "66", "--nz", "66", "--steps", "20", "--warmup", "5"]
+    if launcher != "self-auto":
+        tail += ["--transport", "tcp"]     # "self-auto": no transport named -> RCCL is tried, refuses the shared device, and the library says so and stages through the host
+    if launcher.startswith("self"):
         cmd = [sys.executable] + tail
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", port] + tail
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HEMOCELL_TRANSPORT")}
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -75,4 +76,6 @@ def test_bench_two_ranks_share_the_gpu(gpu, launcher):
     assert j["value"] > 0 and j["config"]["cells"] > 0 and "cpu_baseline" not in j      # the CPU baseline is an N = 1 item
     assert abs(j["value"] - 128 * 66 * 66 / (j["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * j["value"]
     assert "TCP" in j["config"]["parallelism"] and j["slab_schedule"]["host_ms_per_step"] > 0
+    if launcher == "self-auto":
+        assert "RCCL point-to-point is not usable here" in r.stderr
     assert j["slab_schedule"]["records_sent_rank0"] > 0            # cells do sit at the slab faces in this packing

@@ -1,4 +1,4 @@
-"""python profiles/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [skip_launches [iterations]]
+"""python profiles/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [skip_launches [iterations [drop_last]]]
 
 iterations: lattice passes the profiled command made in all (bench.py: warmup + steps + the 10 passes of its "alone" measurement).
 With it the collide kernel's bytes are summed over ALL its launches and divided by that count (bytes per lattice pass, however
@@ -17,7 +17,7 @@ import sys
 NODES = 256 ** 3
 
 
-def per_kernel(path, counter, skip, total=False):
+def per_kernel(path, counter, skip, total=False, drop_last=0):
     acc = {}
     for row in csv.DictReader(open(path)):
         if row["Counter_Name"] != counter:
@@ -28,14 +28,16 @@ def per_kernel(path, counter, skip, total=False):
         acc.setdefault(name, []).append(float(row["Counter_Value"]))
     if total:
         return {k: sum(v) for k, v in acc.items()}
-    return {k: sum(v[skip:]) / max(1, len(v[skip:])) for k, v in acc.items() if len(v) > skip}
+    cut = lambda k, v: v[skip:len(v) - drop_last] if ("collide_stream_kernel" in k and drop_last) else v[skip:]
+    return {k: sum(cut(k, v)) / max(1, len(cut(k, v))) for k, v in acc.items() if len(v) > skip + drop_last}
 
 
 def main():
     skip = int(sys.argv[4]) if len(sys.argv) > 4 else 10
     iterations = int(sys.argv[5]) if len(sys.argv) > 5 else 0
-    fetch = per_kernel(sys.argv[1], "FETCH_SIZE", skip)
-    write = per_kernel(sys.argv[2], "WRITE_SIZE", skip)
+    drop_last = int(sys.argv[6]) if len(sys.argv) > 6 else 0     # bench.py ends with 10 collide launches alone (no spread before them)
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE", skip, drop_last=drop_last)
+    write = per_kernel(sys.argv[2], "WRITE_SIZE", skip, drop_last=drop_last)
     key = [k for k in fetch if "collide_stream_kernel" in k][0]
     if iterations:   # bytes per lattice pass = all launches of the kernel together / passes made
         fetch[key] = per_kernel(sys.argv[1], "FETCH_SIZE", 0, True)[key] / iterations

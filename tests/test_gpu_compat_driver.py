@@ -66,6 +66,13 @@ def test_stretch_driver_matches_python_host_and_band(tmp_path, gpu):
     L.destroy()
 
 
+def _h5_array(path, name):
+    """one dataset of an HDF5 file as a flat float array (through h5dump: no h5py in the image)"""
+    dump = subprocess.run(["/opt/conda/bin/h5dump", "-d", "/" + name, "-y", "-w", "0", path], capture_output=True, text=True).stdout
+    body = dump[dump.index("DATA {") + 6:dump.rindex("}")]
+    return np.array([float(t) for t in body.replace("}", " ").replace(",", " ").split()])
+
+
 def test_pipe_driver_validation_bounds(tmp_path, gpu):
     """tests/validation/pipeflow/test_pipeflow.cpp:87-106 on the synthetic pipe: the cell count stays constant,
     relative apparent viscosity in (1.03, 3.0), mean vertex force below 4 pN"""
@@ -116,6 +123,31 @@ def test_pipe_driver_validation_bounds(tmp_path, gpu):
         assert "( 54, 54, 102, %d )" % c in seg, (name, seg)      # [Nz+2][Ny+2][Nx+2][C]
     for attr in ("numberOfCells", "subdomainSize", "relativePosition", "dxdydz"):
         assert 'ATTRIBUTE "%s"' % attr in hf, attr
+    # ---- values and units, checked against each other and against the CSV summary (all SI: outputInSiUnits is the default,
+    # core/hemoCell.cpp:221-287): positions in m, forces in N, the separate force vectors add up to the total force
+    rbc = os.path.join(d, "RBC.000000000400.p.0.h5")
+    pos = _h5_array(rbc, "Position").reshape(25, 642, 3)
+    cid = _h5_array(rbc, "Cell Id").reshape(25, 642)[:, 0].astype(int)
+    vid = _h5_array(rbc, "Vertex Id").reshape(25, 642)
+    assert (vid == np.arange(642)[None, :]).all()
+    rows = {int(l.split(",")[6]): [float(x) for x in l.split(",")[:5]] for l in csv[1:]}
+    assert sorted(rows) == sorted(cid.tolist())
+    Lx = 100 * 0.5e-6                                                                     # the pipe is periodic along x: the writer wraps vertex by vertex
+    for k, c in enumerate(cid):
+        q = pos[k].copy(); q[:, 0] = q[0, 0] + ((q[:, 0] - q[0, 0] + Lx / 2) % Lx - Lx / 2)   # one contiguous image of the cell
+        dmean = q.mean(axis=0) - np.array(rows[c][:3]); dmean[0] = (dmean[0] + Lx / 2) % Lx - Lx / 2
+        assert np.abs(dmean).max() < 3e-6 * Lx, (c, dmean)                               # cell centre [m] of the CSV = mean of its vertices (float32 datasets)
+        assert 120e-12 < rows[c][3] < 140e-12 and 75e-18 < rows[c][4] < 90e-18            # RBC surface ~ 130 um^2, volume ~ 81 um^3
+    assert 0 < pos[:, :, 0].min() and pos[:, :, 0].max() < 100 * 0.5e-6 and pos[:, :, 1:].min() > 0 and pos[:, :, 1:].max() < 52 * 0.5e-6   # inside the 100 x 52 x 52 box of 0.5 um nodes
+    total = _h5_array(rbc, "Total force")
+    parts = sum(_h5_array(rbc, n) for n in ("Volume force", "Area force", "Bending force", "Link force", "Viscous force"))
+    assert np.abs(total).max() > 0 and np.abs(total - parts).max() <= 2e-6 * np.abs(total).max()   # float32 datasets
+    assert np.abs(total).max() < 50e-12                                                   # N: below the 50 pN force limit
+    fl = os.path.join(d, "Fluid.000000000400.p.0.h5")
+    bnd = _h5_array(fl, "Boundary").reshape(54, 54, 102)
+    assert set(np.unique(bnd)) == {0.0, 1.0} and 0.15 < bnd.mean() < 0.35                 # the pipe wall, one-node envelope included
+    vel = _h5_array(fl, "Velocity").reshape(54, 54, 102, 3)
+    assert np.abs(vel[bnd == 1]).max() == 0.0 and 0 < vel[..., 0].max() < 1e-2           # m/s: no flow in the wall, creeping flow along x in the lumen
 
 
 def test_moving_wall_couette_vs_oracle(orc, gpu):

@@ -84,6 +84,19 @@ inline void writeCellField3D_HDF5(HemoCell &h, HemoCellField &field, const strin
       case OUTPUT_VELOCITY: h5_write_2d(file, "Velocity", vec3(vel, si ? Parameters::dx / Parameters::dt : 1.0), n, 3); break;
       case OUTPUT_FORCE: {   // force_total = force + force_repulsion (core/hemoCellParticleField.cpp:596)
         vector<double> tot(frc); for (size_t i = 0; i < tot.size(); i++) tot[i] += rep[i];
+        // With separate force vectors requested the reference first re-evaluates the model where this iteration is a material
+        // step (separateForceVectors -> applyConstitutiveModel(), :590-598), so its total is the sum of the vectors it writes.
+        // Same here for the OUTPUT (the forces the simulation holds are left alone; the reference overwrites them as a side effect).
+        bool separate = false;
+        for (int v2 : field.desiredOutputVariables) separate = separate || (v2 >= OUTPUT_FORCE_VOLUME && v2 <= OUTPUT_FORCE_INNER_LINK);
+        const long nfull = full_nc * field.numVertex;
+        if (separate && nfull && h.iter % field.timescale == 0) {
+          if (comp.empty()) { comp.resize(18 * (size_t)nfull); hc_check(hcp_mechanics_components(c, (int)field.ctype, comp.data()), "hcp_mechanics_components"); }
+          for (long i = 0; i < nfull; i++) for (int d = 0; d < 3; d++) {
+            double sum = 0; for (int slot = 0; slot < 6; slot++) sum += comp[(size_t)(slot * 3 * nfull + 3 * i + d)];
+            tot[(size_t)(3 * (fv + i) + d)] = sum + rep[(size_t)(3 * (fv + i) + d)];
+          }
+        }
         h5_write_2d(file, "Total force", vec3(tot, si ? Parameters::df : 1.0), n, 3); break; }
       case OUTPUT_FORCE_VOLUME: case OUTPUT_FORCE_AREA: case OUTPUT_FORCE_BENDING: case OUTPUT_FORCE_LINK: case OUTPUT_FORCE_VISC: case OUTPUT_FORCE_INNER_LINK: {
         const long nfull = full_nc * field.numVertex;
@@ -126,6 +139,10 @@ inline void writeFluidField_HDF5(HemoCell &h, const string &dir) {
   const size_t nn = (size_t)nx * ny * nz;
   vector<double> rho(nn), u(3 * nn);
   hc_check(hcl_download_rho_u(d, rho.data(), u.data()), "hcl_download_rho_u");
+  // cell.computeVelocity / computeDensity go through the node's dynamics (io/FluidHdf5IO.hh:223,273): a BounceBack node
+  // answers zero velocity and the density it was constructed with, whatever its populations hold
+  if (!L->bounce_back.empty())
+    for (size_t k = 0; k < nn; k++) if (L->bounce_back[k + (size_t)x0 * ny * nz]) { rho[k] = L->bb_rho; u[3 * k] = u[3 * k + 1] = u[3 * k + 2] = 0; }
   const string fileName = dir + "/Fluid." + zeroPadNumber(h.iter) + ".p." + std::to_string(global.rank) + ".h5";
   hid_t file = H5Fcreate(fileName.c_str(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
   double dx = Parameters::dx, dt = Parameters::dt; long it = h.iter; int id = global.rank;

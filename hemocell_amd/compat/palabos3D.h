@@ -68,7 +68,7 @@ struct ForcedD3Q19Descriptor {
 
 // ---- dynamics objects: only their identity and omega matter
 template <typename U, template <typename> class D>
-struct Dynamics { virtual ~Dynamics() {} virtual bool isBoundary() const { return false; } virtual U getOmega() const { return U(1); } };
+struct Dynamics { virtual ~Dynamics() {} virtual bool isBoundary() const { return false; } virtual U getOmega() const { return U(1); } virtual U wallDensity() const { return U(1); } };
 template <typename U, template <typename> class D>
 struct GuoExternalForceBGKdynamics : Dynamics<U, D> {
   U omega;
@@ -77,8 +77,10 @@ struct GuoExternalForceBGKdynamics : Dynamics<U, D> {
 };
 template <typename U, template <typename> class D>
 struct BounceBack : Dynamics<U, D> {
-  explicit BounceBack(U = U(1)) {}
+  U rho;   // what computeDensity() answers on such a node (Palabos BounceBack); computeVelocity() answers zero
+  explicit BounceBack(U rho_ = U(1)) : rho(rho_) {}
   bool isBoundary() const override { return true; }
+  U wallDensity() const override { return rho; }
 };
 
 struct MultiBlockManagement3D { plint nx = 0, ny = 0, nz = 0, envelope = 1; };
@@ -197,10 +199,17 @@ class MultiBlockLattice3D {
     return 3 + (int)wall_u.size() - 1;
   }
   std::vector<std::array<U, 3>> wall_u;
+  void note_wall(size_t k, bool wall, const Dynamics<U, D> *dyn) {
+    if (wall && bounce_back.empty()) bounce_back.assign(mask.size(), 0);
+    if (!bounce_back.empty()) bounce_back[k] = wall ? 1 : 0;
+    if (wall) bb_rho = dyn->wallDensity();
+  }
 
   plint nx, ny, nz;
   U omega;
   std::vector<uint8_t> mask;   // 1 = BounceBack / isBoundary, 3..6 = velocity wall classes
+  std::vector<uint8_t> bounce_back;   // 1 where a BounceBack dynamics was assigned (output: velocity 0, density bb_rho); empty = none
+  U bb_rho = 1;
   Periodicity3D per;
   U eq_rho = 1; U eq_u[3] = {0, 0, 0};
   U body[3] = {0, 0, 0};
@@ -217,7 +226,7 @@ void defineDynamics(MultiBlockLattice3D<U, D> &lattice, MultiScalarField3D<int> 
   for (plint x = box.x0; x <= box.x1; x++)
     for (plint y = box.y0; y <= box.y1; y++)
       for (plint z = box.z0; z <= box.z1; z++)
-        if (flags.get(x, y, z) == whichFlag) lattice.mask[((size_t)x * lattice.ny + y) * lattice.nz + z] = wall ? 1 : 0;
+        if (flags.get(x, y, z) == whichFlag) { const size_t k = ((size_t)x * lattice.ny + y) * lattice.nz + z; lattice.mask[k] = wall ? 1 : 0; lattice.note_wall(k, wall, dyn); }
   if (lattice.before_access) lattice.before_access();
   lattice.dirty_layout = true;
   delete dyn;
@@ -228,7 +237,7 @@ void defineDynamics(MultiBlockLattice3D<U, D> &lattice, Box3D box, Dynamics<U, D
   const bool wall = dyn->isBoundary();
   for (plint x = box.x0; x <= box.x1; x++)
     for (plint y = box.y0; y <= box.y1; y++)
-      for (plint z = box.z0; z <= box.z1; z++) lattice.mask[((size_t)x * lattice.ny + y) * lattice.nz + z] = wall ? 1 : 0;
+      for (plint z = box.z0; z <= box.z1; z++) { const size_t k = ((size_t)x * lattice.ny + y) * lattice.nz + z; lattice.mask[k] = wall ? 1 : 0; lattice.note_wall(k, wall, dyn); }
   lattice.dirty_layout = true;
   delete dyn;
 }

@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--copy-reps", type=int, default=40, help="repetitions of the 1 GiB copy that measures this GPU's copy bandwidth")
     ap.add_argument("--nx", type=int, default=256, help="slab thickness per GPU")
     ap.add_argument("--ny", type=int, default=256)
     ap.add_argument("--nz", type=int, default=256)
@@ -198,6 +199,11 @@ def main():
         if world > 1:
             slab.barrier()
 
+    # the GPU in hand: device-to-device copy rate (1 GiB, read + write counted), printed next to the roofline.  Measured
+    # before the run, while nothing else is queued on the GPU
+    cbw = C.c_double()
+    host.check(lib.hc_measure_copy_bandwidth(1 << 30, args.copy_reps, C.byref(cbw)))
+    barrier()
     runner.run(args.warmup)
     runner.slab_stats(reset=True)
     lib.hc_profile_reset()
@@ -266,8 +272,6 @@ def main():
                     traffic, traffic_per_node = tj["hbm_bytes_per_launch"], tj["hbm_bytes_per_node"]
                     traffic_src = "profiles/%s (rocprofv3 --pmc, %.1f B/node, kernel build %s)" % (tf, traffic_per_node, tag)
                     break
-        cbw = C.c_double()
-        host.check(lib.hc_measure_copy_bandwidth(1 << 30, 10, C.byref(cbw)))
         out = {
             "metric": "MLUPS + cell-vertex updates/s, 256^3 pipeflow 10% Hct",
             "value": mlups, "unit": "MLUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -80,6 +80,7 @@ SIGNATURES = {
     "hcl_download_populations": (C.c_int, [VP, c_double_p]),
     "hcl_upload_populations": (C.c_int, [VP, c_double_p]),
     "hcl_download_rho_u": (C.c_int, [VP, c_double_p, c_double_p]),
+    "hcl_download_pi_neq": (C.c_int, [VP, c_double_p]),
     "hcl_download_ibm_force": (C.c_int, [VP, c_double_p]),
     "hcl_zero_ibm_force": (C.c_int, [VP]),
     "hcl_halo_doubles": (C.c_size_t, [VP, C.c_int]),

@@ -156,12 +156,7 @@ inline void writeFluidField_HDF5(HemoCell &h, const string &dir) {
   H5LTset_attribute_int(file, "/", "numberOfCells", &ncells, 1); H5LTset_attribute_int(file, "/", "subdomainSize", sub, 3);
   H5LTset_attribute_float(file, "/", "relativePosition", rel, 3); H5LTset_attribute_float(file, "/", "dxdydz", dxdydz, 3);
   auto src = [&](plint v, plint n, bool per) { if (v < 0 || v >= n) return per ? ((v % n) + n) % n : std::min<plint>(std::max<plint>(v, 0), n - 1); return v; };
-  auto write4 = [&](const string &name, int C, const std::function<float(size_t, int)> &val) {
-    vector<float> out((size_t)(Nx * Ny * Nz) * C); size_t o = 0;
-    for (plint z = -1; z <= nz; z++) for (plint y = -1; y <= ny; y++) for (plint x = -1; x <= nx; x++) {
-      const size_t k = ((size_t)src(x, nx, L->per.p[0] && L->world == 1) * ny + src(y, ny, L->per.p[1])) * nz + src(z, nz, L->per.p[2]);   // a slab's x-envelope repeats its face
-      for (int cidx = 0; cidx < C; cidx++) out[o++] = val(k, cidx);
-    }
+  auto write_raw = [&](const string &name, int C, const vector<float> &out) {
     hsize_t dim[4] = {Nz, Ny, Nx, (hsize_t)C}, chunk[4] = {std::min<hsize_t>(1000, Nz), std::min<hsize_t>(1000, Ny), std::min<hsize_t>(1000, Nx), (hsize_t)C};
     hid_t sid = H5Screate_simple(4, dim, NULL), pl = H5Pcreate(H5P_DATASET_CREATE);
     H5Pset_chunk(pl, 4, chunk); H5Pset_deflate(pl, 7);
@@ -169,11 +164,68 @@ inline void writeFluidField_HDF5(HemoCell &h, const string &dir) {
     H5Dwrite(did, H5T_NATIVE_FLOAT, H5S_ALL, H5S_ALL, H5P_DEFAULT, out.data());
     H5Dclose(did); H5Pclose(pl); H5Sclose(sid);
   };
+  auto write4 = [&](const string &name, int C, const std::function<float(size_t, int)> &val) {
+    vector<float> out((size_t)(Nx * Ny * Nz) * C); size_t o = 0;
+    for (plint z = -1; z <= nz; z++) for (plint y = -1; y <= ny; y++) for (plint x = -1; x <= nx; x++) {
+      const size_t k = ((size_t)src(x, nx, L->per.p[0] && L->world == 1) * ny + src(y, ny, L->per.p[1])) * nz + src(z, nz, L->per.p[2]);   // a slab's x-envelope repeats its face
+      for (int cidx = 0; cidx < C; cidx++) out[o++] = val(k, cidx);
+    }
+    write_raw(name, C, out);
+  };
+  const size_t xoff = (size_t)x0 * ny * nz;
+  auto is_bb = [&](size_t k) { return !L->bounce_back.empty() && L->bounce_back[k + xoff] != 0; };
+  vector<double> pi;   // off-equilibrium momentum flux, fetched once if a stress or strain-rate field is asked for
+  auto need_pi = [&]() { if (pi.empty()) { pi.resize(6 * nn); hc_check(hcl_download_pi_neq(d, pi.data()), "hcl_download_pi_neq"); } };
+  // source node of output node (x, y, z), each in -1 .. n: the envelope repeats the face (or the periodic image)
+  auto node_of = [&](plint x, plint y, plint z) { return ((size_t)src(x, nx, L->per.p[0] && L->world == 1) * ny + src(y, ny, L->per.p[1])) * nz + src(z, nz, L->per.p[2]); };
   for (int var : h.fluidOutputs) {
     if (var == OUTPUT_VELOCITY) write4("Velocity", 3, [&](size_t k, int cidx) { return (float)(u[3 * k + cidx] * (si ? Parameters::dx / Parameters::dt : 1.0)); });
     else if (var == OUTPUT_FORCE) write4("Force", 3, [&](size_t, int cidx) { return (float)(L->body[cidx] * (si ? Parameters::df : 1.0)); });
     else if (var == OUTPUT_DENSITY) write4("Density", 1, [&](size_t k, int) { return (float)(rho[k] * (si ? Parameters::df / (Parameters::dx * Parameters::dx) : 1.0)); });
-    else if (var == OUTPUT_BOUNDARY) write4("Boundary", 1, [&](size_t k, int) { return L->mask[k + (size_t)x0 * ny * nz] ? 1.f : 0.f; });
+    else if (var == OUTPUT_BOUNDARY) write4("Boundary", 1, [&](size_t k, int) { return L->mask[k + xoff] ? 1.f : 0.f; });
+    else if (var == OUTPUT_OMEGA)   // getDynamics().getOmega(), scaled like a stress in SI as the reference does (io/FluidHdf5IO.hh:352-372); a BounceBack node has none
+      write4("Omega", 1, [&](size_t k, int) { return (float)((is_bb(k) ? 0.0 : (double)L->omega) * (si ? Parameters::df / (Parameters::dx * Parameters::dx) : 1.0)); });
+    else if (var == OUTPUT_SHEAR_STRESS) {   // Cell::computeShearStress (io/FluidHdf5IO.hh:404-432): (omega/2 - 1) PiNeq in the bulk, zero on BounceBack nodes
+      need_pi();
+      const double pre = 0.5 * (double)L->omega - 1.0;
+      write4("ShearStress", 6, [&](size_t k, int cidx) { return (float)(is_bb(k) ? 0.0 : pre * pi[6 * k + cidx] * (si ? Parameters::df / (Parameters::dx * Parameters::dx) : 1.0)); });
+    } else if (var == OUTPUT_STRAIN_RATE) {   // computeStrainRateFromStress (io/FluidHdf5IO.hh:497-552): -omega / (2 cs2 rho) PiNeq
+      need_pi();
+      write4("StrainRate", 6, [&](size_t k, int cidx) { return (float)(is_bb(k) ? 0.0 : -1.5 * (double)L->omega / rho[k] * pi[6 * k + cidx] * (si ? 1.0 / Parameters::dt : 1.0)); });
+    } else if (var == OUTPUT_SHEAR_RATE) {   // central differences of computeVelocity (io/FluidHdf5IO.hh:434-495); row a*3+b = d u_a / d x_b
+      vector<float> out((size_t)(Nx * Ny * Nz) * 9); size_t o = 0;
+      for (plint z = -1; z <= nz; z++) for (plint y = -1; y <= ny; y++) for (plint x = -1; x <= nx; x++) {
+        const size_t p[3] = {node_of(x + 1, y, z), node_of(x, y + 1, z), node_of(x, y, z + 1)}, m[3] = {node_of(x - 1, y, z), node_of(x, y - 1, z), node_of(x, y, z - 1)};
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) out[o++] = (float)((u[3 * p[b] + a] - u[3 * m[b] + a]) / 2 * (si ? 1.0 / Parameters::dt : 1.0));
+      }
+      write_raw("ShearRate", 9, out);
+    } else if (var == OUTPUT_CELL_DENSITY) {   // vertices per node, one dataset per cell type (io/FluidHdf5IO.hh:374-402)
+      hc_cells *c = h.cellfields->device();
+      long nvt = 0; hcp_counts(c, &nvt, nullptr, nullptr);
+      vector<double> pos(3 * (size_t)nvt); if (nvt) hcp_download(c, 0, pos.data());
+      vector<unsigned char> alive((size_t)nvt, 1); if (nvt) hc_check(hcp_download_alive(c, alive.data()), "hcp_download_alive");
+      for (unsigned int t = 0; t < h.cellfields->size(); t++) {
+        long fv = 0, nc = 0; hcp_type_range(c, (int)t, &fv, &nc);
+        const HemoCellField &cf = *(*h.cellfields)[t];
+        vector<float> out((size_t)(Nx * Ny * Nz), 0.f);
+        for (long i = fv; i < fv + nc * cf.numVertex; i++) {
+          if (!alive[(size_t)i]) continue;
+          // the reference indexes the (Nx+2)-wide array with the node coordinate itself, i.e. one node towards the origin of
+          // where the other datasets put that node (:388-393); kept, so that files compare
+          plint q[3]; const plint dims[3] = {L->nx, ny, nz};
+          for (int a = 0; a < 3; a++) { q[a] = (plint)std::floor(pos[(size_t)(3 * i + a)] + 0.5); if (L->per.p[a]) q[a] = ((q[a] % dims[a]) + dims[a]) % dims[a]; }
+          q[0] -= x0;
+          if (q[0] < 0 || q[0] >= nx || q[1] < 0 || q[1] >= ny || q[2] < 0 || q[2] >= nz) continue;   // findParticles(localDomain): this block's vertices
+          out[(size_t)q[0] + (size_t)q[1] * Nx + (size_t)q[2] * Nx * Ny] += 1.f;
+        }
+        if (si) for (float &v : out) v *= (float)cf.volumeFractionOfLspPerNode;
+        write_raw("CellDensity_" + cf.name, 1, out);
+      }
+    } else if (var == OUTPUT_BINDING_SITES || var == OUTPUT_INTERIOR_POINTS) {   // neither feature exists here: what the reference writes without them (:306-350)
+      pcout << (var == OUTPUT_BINDING_SITES ? "(FluidHdf5) (Error) OUTPUT_BINDING_SITES requested, but binding sites not used, outputting a zero field"
+                                            : "(FluidHdf5) (Error) OUTPUT_INTERIOR_POINTS requested, but interior viscosity not used, outputting a zero field") << endl;
+      write_raw(var == OUTPUT_BINDING_SITES ? "BindingSites" : "InteriorPoints", 1, vector<float>((size_t)(Nx * Ny * Nz), 0.f));
+    }
   }
   H5Fclose(file);
 }

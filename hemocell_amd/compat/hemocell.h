@@ -39,7 +39,12 @@
 #define OUTPUT_CELL_DENSITY 9
 #define OUTPUT_SHEAR_STRESS 10
 #define OUTPUT_INNER_LINKS 11
+#define OUTPUT_OMEGA 12
 #define OUTPUT_BOUNDARY 13
+#define OUTPUT_BINDING_SITES 14
+#define OUTPUT_INTERIOR_POINTS 15
+#define OUTPUT_SHEAR_RATE 16
+#define OUTPUT_STRAIN_RATE 17
 #define OUTPUT_RES_TIME 18
 #define param Parameters
 #ifndef PI
@@ -298,6 +303,7 @@ class HemoCellField {
   T minimumDistanceFromSolid = 0;   // micrometres.  core/hemoCellField.h:64 declares it unsigned int (0.5 -> 0); the fraction is kept here
                                     // because only then does examples/pipeflow keep the 42 cells the reference's tests assert
   int numVertex = 0, numTriangles = 0;
+  T volume = 0, volumeFractionOfLspPerNode = 0;   // core/hemoCellField.h:60-61, from <MaterialModel><Volume> (core/hemoCellField.cpp:92-98)
   plb::MeshMetrics<T> *meshmetric = nullptr;
   CellMechanics *mechanics = nullptr;
   void (*kernelMethod)(plb::BlockLattice3D<T, DESCRIPTOR> &, HemoCellParticle &) = interpolationCoefficientsPhi2;   // core/hemoCellField.h:67
@@ -454,6 +460,16 @@ class HemoCell {
 
   void latticeEquilibrium(T rho, hemo::Array<T, 3> vel) { lattice->eq_rho = rho; for (int d = 0; d < 3; d++) lattice->eq_u[d] = vel[d]; lattice->dirty_layout = true; }
   void initializeCellfield() { cellfields = new HemoCellFields(*this); }
+  // core/hemoCell.cpp:438-474: the lattice from the block management alone, GuoExternalForceBGKdynamics(1/tau) as the bulk
+  // dynamics.  <domain><mABx/y/z> (an explicit block layout) does not apply: every rank holds one x-slab.
+  void initializeLattice(plb::MultiBlockManagement3D const &management) {
+    if (lattice) { flush(); delete lattice; lattice = nullptr; }
+    hlog << "(HemoCell) Using default domain management." << endl;
+    lattice = new plb::MultiBlockLattice3D<T, DESCRIPTOR>(management, plb::defaultMultiBlockPolicy3D().getBlockCommunicator(),
+                                                          plb::defaultMultiBlockPolicy3D().getCombinedStatistics(),
+                                                          plb::defaultMultiBlockPolicy3D().getMultiCellAccess<T, DESCRIPTOR>(),
+                                                          new plb::GuoExternalForceBGKdynamics<T, DESCRIPTOR>(1.0 / param::tau));
+  }
 
   template <class Mechanics>
   void addCellType(string name, int constructType) {
@@ -582,6 +598,10 @@ inline void HemoCellField::create_device_type(int model) {
   meshmetric = new plb::MeshMetrics<T>();
   meshmetric->volume = sc[0]; meshmetric->meanLength = sc[2]; meshmetric->numVertices = sz[0]; meshmetric->numTriangles = sz[1];
   for (double a : area) meshmetric->surface += a;
+  try {   // core/hemoCellField.cpp:92-98
+    volume = m["MaterialModel"]["Volume"].read<T>();
+    volumeFractionOfLspPerNode = (volume / numVertex) / std::pow(Parameters::dx * 1e6, 3);
+  } catch (std::invalid_argument &) { hlog << "(HemoCell) (WARNING) (AddCellType) Volume of celltype " << name << " not present, volume set to zero" << endl; }
 }
 
 // mechanics/commonCellConstants.cpp:70-409: the tables are built by the library (csrc/mesh.cpp) together with the mesh;

@@ -294,6 +294,41 @@ __global__ void rho_u_kernel(LatArgs a, double *rho, double *u) {
   u[3 * o + 2] = j2 * invRho + (a.bz + a.Fin[2 * a.npad + node]) / 2.0;
 }
 
+// Off-equilibrium part of the momentum-flux tensor, as Palabos' momentTemplates::compute_rhoBar_j_PiNeq forms it from the
+// stored populations f_i - t_i: Pi_ab = sum_i c_ia c_ib fbar_i - j_a j_b / rho - cs2 rhoBar delta_ab, components in the
+// order xx, xy, xz, yy, yz, zz.  Output fields only (shear stress, strain rate); nothing on the step path reads it.
+__global__ void pi_neq_kernel(LatArgs a, double *pi) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.plane) return;
+  const int x = a.x_begin + blockIdx.y;
+  const int y = p / a.nz, z = p - y * a.nz;
+  const long node = (long)(x + HALO) * a.xs + p;
+  const Nbr n = neighbours(a, x, y, z);
+  double f[HC_Q];
+  pull(a.fin, a.qs, node, n, f);
+  double rhoBar, j0, j1, j2;
+  moments(f, rhoBar, j0, j1, j2);
+  const double invRho = 1.0 / (1.0 + rhoBar);
+  double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+#define M(Q, CX, CY, CZ)                       \
+  if (CX * CX) xx += f[Q];                     \
+  if (CX * CY == 1) xy += f[Q]; else if (CX * CY == -1) xy += -f[Q]; \
+  if (CX * CZ == 1) xz += f[Q]; else if (CX * CZ == -1) xz += -f[Q]; \
+  if (CY * CY) yy += f[Q];                     \
+  if (CY * CZ == 1) yz += f[Q]; else if (CY * CZ == -1) yz += -f[Q]; \
+  if (CZ * CZ) zz += f[Q];
+  FOR_Q(M)
+#undef M
+  const double cs2 = 1.0 / 3.0;
+  const long o = 6 * ((long)x * a.plane + p);
+  pi[o] = xx - invRho * j0 * j0 - cs2 * rhoBar;
+  pi[o + 1] = xy - invRho * j0 * j1;
+  pi[o + 2] = xz - invRho * j0 * j2;
+  pi[o + 3] = yy - invRho * j1 * j1 - cs2 * rhoBar;
+  pi[o + 4] = yz - invRho * j1 * j2;
+  pi[o + 5] = zz - invRho * j2 * j2 - cs2 * rhoBar;
+}
+
 __global__ void force_aos_kernel(LatArgs a, double *F) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= a.plane) return;
@@ -719,6 +754,19 @@ int hcl_download_rho_u(hc_lattice *L, double *rho, double *u) {
   HC_HIP(hipGetLastError());
   HC_HIP(hipMemcpyAsync(rho, L->scratch, n * sizeof(double), hipMemcpyDeviceToHost, hc::stream()));
   HC_HIP(hipMemcpyAsync(u, L->scratch + n, 3 * n * sizeof(double), hipMemcpyDeviceToHost, hc::stream()));
+  HC_HIP(hipStreamSynchronize(hc::stream()));
+  return HC_OK;
+}
+
+int hcl_download_pi_neq(hc_lattice *L, double *pi) {
+  HC_REQUIRE(L && pi, "hcl_download_pi_neq: null pointer");
+  if (L->n_slabs > 1) { const int rc = hcl_slab_refresh_halos(L, 2); if (rc != HC_OK) return rc; }
+  const size_t n = (size_t)L->nx * L->plane;
+  int rc = ensure_scratch(L, n * 6); if (rc != HC_OK) return rc;
+  LatArgs a = make_args(L);
+  hipLaunchKernelGGL(pi_neq_kernel, plane_grid(L, L->nx), dim3(256), 0, hc::stream(), a, L->scratch);
+  HC_HIP(hipGetLastError());
+  HC_HIP(hipMemcpyAsync(pi, L->scratch, 6 * n * sizeof(double), hipMemcpyDeviceToHost, hc::stream()));
   HC_HIP(hipStreamSynchronize(hc::stream()));
   return HC_OK;
 }

@@ -128,6 +128,12 @@ class Lattice:
         check(self.lib.hcl_download_rho_u(self.ptr, dptr(rho), dptr(u)))
         return rho, u
 
+    def pi_neq(self):
+        """off-equilibrium momentum flux (xx, xy, xz, yy, yz, zz) per node"""
+        pi = np.empty((self.n, 6), dtype=np.float64)
+        check(self.lib.hcl_download_pi_neq(self.ptr, dptr(pi)))
+        return pi
+
     def ibm_force(self):
         F = np.empty((self.n, 3), dtype=np.float64)
         check(self.lib.hcl_download_ibm_force(self.ptr, dptr(F)))

@@ -147,6 +147,9 @@ int hcl_download_populations(hc_lattice *L, double *f_aos);
 int hcl_upload_populations(hc_lattice *L, const double *f_aos);
 /* rho[n] and u[n][3] = Cell::computeVelocity (j/rho + F/2), local bulk nodes */
 int hcl_download_rho_u(hc_lattice *L, double *rho, double *u);
+/* pi[n][6] = the off-equilibrium momentum flux of the post-stream populations (xx, xy, xz, yy, yz, zz), the quantity
+ * Cell::computeShearStress and computeStrainRateFromStress scale (io/FluidHdf5IO.hh:419-443, :497-552), local bulk nodes */
+int hcl_download_pi_neq(hc_lattice *L, double *pi);
 /* IBM force field currently accumulated (without the body force), [node][3] */
 /* FluidInfo::calculate{Velocity,Force}Statistics (helper/fluidInfo.cpp:33-118) as a device reduction: out = {min, max,
  * sum} of the magnitude over the non-boundary bulk nodes of this slab, *n_nodes their number.  what: 0 =

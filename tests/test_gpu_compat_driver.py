@@ -1,6 +1,7 @@
 """GPU runs of the example drivers written against the C++ facade; the assertions are the reference's own
 validation bounds, so these read like tests/validation/* of the reference."""
 import os
+import shutil
 import subprocess
 
 import numpy as np
@@ -68,7 +69,7 @@ def test_stretch_driver_matches_python_host_and_band(tmp_path, gpu):
 
 def _h5_array(path, name):
     """one dataset of an HDF5 file as a flat float array (through h5dump: no h5py in the image)"""
-    dump = subprocess.run(["/opt/conda/bin/h5dump", "-d", "/" + name, "-y", "-w", "0", path], capture_output=True, text=True).stdout
+    dump = subprocess.run(["/opt/conda/bin/h5dump", "-d", "/" + name, "-y", "-w", "0", "-m", "%.9g", path], capture_output=True, text=True).stdout
     body = dump[dump.index("DATA {") + 6:dump.rindex("}")]
     return np.array([float(t) for t in body.replace("}", " ").replace(",", " ").split()])
 
@@ -152,6 +153,68 @@ def test_pipe_driver_validation_bounds(tmp_path, gpu):
     assert ux[26, 26] > 0.5 * ux.max() and ux[26, 26] > 3 * ux[26, 4]                     # fastest near the axis, slow next to the wall
     rho = _h5_array(fl, "Density").reshape(54, 54, 102)
     assert (rho[bnd == 1] == rho[bnd == 1][0]).all() and abs(rho[bnd == 0].mean() / rho[bnd == 1][0] - 1) < 1e-2   # BounceBack(1.) nodes answer rho = 1 (in SI here)
+
+
+@pytest.mark.skipif(not HAVE_HDF5, reason="no HDF5 in this image")
+def test_every_fluid_output_variable(tmp_path, gpu):
+    """io/FluidHdf5IO.hh:139-199: Velocity, Density, Force, Boundary, Omega, ShearStress, ShearRate, StrainRate,
+    CellDensity_<type>, BindingSites, InteriorPoints of a settled pipe flow with one RBC, checked against each other.
+    Palabos' prefactors of computeShearStress / computeStrainRateFromStress cannot be read here (parity unpinned); the
+    physics pins them: strain rate = symmetric velocity gradient, stress = 2 mu strain rate."""
+    exe = _build(tmp_path, "tests/drivers/fluid_outputs.cpp")
+    d = str(tmp_path / "case"); shutil.copytree(os.path.join(ROOT, "tests", "golden", "shear_case"), d)
+    for f in os.listdir(d):
+        os.chmod(os.path.join(d, f), 0o644)
+    open(os.path.join(d, "RBC.pos"), "w").write("1\n8.0 8.25 8.25 0 0 0\n")          # x = 16 lu, on the axis
+    r = subprocess.run([exe, "config.xml"], cwd=d, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "OUTPUT_BINDING_SITES requested, but binding sites not used" in r.stdout and "OUTPUT_INTERIOR_POINTS requested" in r.stdout
+    par = [l.split() for l in r.stdout.splitlines() if l.startswith("PARAMS")][0]
+    tau, dx, dt, df, frac = (float(par[k]) for k in (2, 4, 6, 8, 10))
+    f = os.path.join(d, "tmp", "hdf5", "000000000010", "Fluid.000000000010.p.0.h5")
+    hdr = subprocess.run(["/opt/conda/bin/h5dump", "-H", f], capture_output=True, text=True).stdout
+    for name, c in (("Velocity", 3), ("Density", 1), ("Force", 3), ("Boundary", 1), ("Omega", 1), ("ShearStress", 6), ("ShearRate", 9), ("StrainRate", 6),
+                    ("CellDensity_RBC", 1), ("BindingSites", 1), ("InteriorPoints", 1)):
+        seg = hdr[hdr.index('DATASET "%s"' % name):][:300]
+        assert "( 36, 36, 66, %d )" % c in seg, (name, seg)
+    N = (36, 36, 66)
+    vel = _h5_array(f, "Velocity").reshape(N + (3,))
+    bnd = _h5_array(f, "Boundary").reshape(N)
+    umax = vel[..., 0].max() * dt / dx
+    assert 0.017 < umax < 0.023                                                       # lattice units: the parabola the driving force was chosen for
+    # ---- ShearRate[3a+b] = d u_a / d x_b, central differences of the Velocity dataset itself (float32 both)
+    sr = _h5_array(f, "ShearRate").reshape(N + (3, 3))
+    inner = (slice(1, -1),) * 3
+    for b, axis in ((0, 2), (1, 1), (2, 0)):                                          # x is the fastest index of the file
+        grad = (np.roll(vel, -1, axis=axis) - np.roll(vel, 1, axis=axis)) / (2 * dx)
+        err = np.abs(sr[..., :, b] - grad)[inner]
+        assert err.max() <= 2e-6 * np.abs(sr).max(), (b, err.max(), np.abs(sr).max())
+    # ---- StrainRate (xx, xy, xz, yy, yz, zz) against the symmetric part of that gradient: bulk nodes three nodes off the
+    # wall, half the pipe away from the cell
+    st = _h5_array(f, "StrainRate").reshape(N + (6,))
+    sym = 0.5 * (sr + np.swapaxes(sr, -1, -2))
+    zz, yy = np.meshgrid(np.arange(36) - 1 - 16.5, np.arange(36) - 1 - 16.5, indexing="ij")
+    bulk = (np.sqrt(zz ** 2 + yy ** 2) < 12.5)[:, :, None] & (np.arange(66)[None, None, :] > 40) & (np.arange(66)[None, None, :] < 60)
+    scale = np.abs(sym[bulk]).max()
+    for k, (a, b) in enumerate(((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))):
+        assert np.abs(st[..., k] - sym[..., a, b])[bulk].max() < 0.03 * scale, (k, np.abs(st[..., k] - sym[..., a, b])[bulk].max(), scale)
+    assert scale > 1e3                                                                 # 1/s: a real gradient (u_max / R ~ 0.02 / 16 / dt)
+    # ---- ShearStress = 2 rho nu StrainRate: [Pa] = 2 * (rho_l * 1025 kg/m3) * 1.1e-6 m2/s * [1/s]
+    ss = _h5_array(f, "ShearStress").reshape(N + (6,))
+    rho = _h5_array(f, "Density").reshape(N) / (df / dx ** 2)
+    fluid = bnd == 0
+    want = 2 * 1025.0 * 1.1e-6 * rho[..., None] * st
+    assert np.abs(ss - want)[fluid].max() < 1e-5 * np.abs(ss).max() and np.abs(ss).max() > 0
+    assert np.abs(ss[bnd == 1]).max() == 0 and np.abs(st[bnd == 1]).max() == 0
+    # ---- Omega: 1 / tau on bulk nodes (scaled like a stress, as the reference scales it), none on BounceBack nodes
+    om = _h5_array(f, "Omega").reshape(N)
+    assert np.allclose(om[fluid], (1.0 / tau) * df / dx ** 2, rtol=1e-6) and (om[bnd == 1] == 0).all()
+    # ---- CellDensity: every vertex counted once at its nearest node (times the volume fraction per vertex in SI)
+    cd = _h5_array(f, "CellDensity_RBC").reshape(N)
+    assert abs(cd.sum() / frac - 642) < 1e-2 and abs(frac - 90.0 / 642 / 0.125) < 1e-6
+    zs, ys, xs = np.nonzero(cd)
+    assert 4 < xs.min() and xs.max() < 30 and 5 < ys.min() and ys.max() < 30            # around x = 16 (+ the few steps it drifted), on the axis
+    assert (_h5_array(f, "BindingSites") == 0).all() and (_h5_array(f, "InteriorPoints") == 0).all()
 
 
 def test_moving_wall_couette_vs_oracle(orc, gpu):

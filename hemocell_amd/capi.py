@@ -72,6 +72,7 @@ SIGNATURES = {
     "hcl_destroy": (C.c_int, [VP]),
     "hcl_set_mask": (C.c_int, [VP, VP]),
     "hcl_init_equilibrium": (C.c_int, [VP, C.c_double, c_double_p]),
+    "hcl_set_body_force_regions": (C.c_int, [VP, C.c_int, C.POINTER(C.c_int), c_double_p]),
     "hcl_set_body_force": (C.c_int, [VP, c_double_p]),
     "hcl_set_wall_velocity": (C.c_int, [VP, C.c_int, c_double_p]),
     "hcl_collide_stream": (C.c_int, [VP, C.c_int]),

@@ -180,7 +180,10 @@ inline void writeFluidField_HDF5(HemoCell &h, const string &dir) {
   auto node_of = [&](plint x, plint y, plint z) { return ((size_t)src(x, nx, L->per.p[0] && L->world == 1) * ny + src(y, ny, L->per.p[1])) * nz + src(z, nz, L->per.p[2]); };
   for (int var : h.fluidOutputs) {
     if (var == OUTPUT_VELOCITY) write4("Velocity", 3, [&](size_t k, int cidx) { return (float)(u[3 * k + cidx] * (si ? Parameters::dx / Parameters::dt : 1.0)); });
-    else if (var == OUTPUT_FORCE) write4("Force", 3, [&](size_t, int cidx) { return (float)(L->body[cidx] * (si ? Parameters::df : 1.0)); });
+    else if (var == OUTPUT_FORCE) {   // the external field as the driver left it (io/FluidHdf5IO.hh:240-262)
+      const auto ext = L->external_now();
+      write4("Force", 3, [&](size_t k, int cidx) { return (float)(ext.at(x0 + (plint)(k / ((size_t)ny * nz)), (plint)(k / (size_t)nz % (size_t)ny), (plint)(k % (size_t)nz))[cidx] * (si ? Parameters::df : 1.0)); });
+    }
     else if (var == OUTPUT_DENSITY) write4("Density", 1, [&](size_t k, int) { return (float)(rho[k] * (si ? Parameters::df / (Parameters::dx * Parameters::dx) : 1.0)); });
     else if (var == OUTPUT_BOUNDARY) write4("Boundary", 1, [&](size_t k, int) { return L->mask[k + xoff] ? 1.f : 0.f; });
     else if (var == OUTPUT_OMEGA)   // getDynamics().getOmega(), scaled like a stress in SI as the reference does (io/FluidHdf5IO.hh:352-372); a BounceBack node has none

@@ -527,6 +527,7 @@ class HemoCell {
   // flush first.  What a driver sees (iter, statistics, output, forces it adds between iterations) is unchanged.
   void iterate() {
     if (!lattice->before_access) lattice->before_access = [this] { flush(); };
+    lattice->sync_force();   // what the driver wrote since the last iteration zeroed the field; usually the same force again
     if (!pending) {   // first queued iteration: make sure everything it needs exists and settings are pushed
       hc_cells *c = cellfields->device();
       if (boundaryRepulsionEnabled && !boundaryRepulsionPushed) { hc_check(hcp_set_boundary_repulsion(c, boundaryRepulsionConstant_, boundaryRepulsionCutoff_, (int)boundaryRepulsionTimescale), "hcp_set_boundary_repulsion"); boundaryRepulsionPushed = true; }
@@ -536,6 +537,7 @@ class HemoCell {
     }
     const bool particle_step = iter % cellfields->particleVelocityUpdateTimescale == 0;
     pending++; iter++;
+    lattice->force_cleared = true;   // core/hemoCell.cpp:369-371: the iteration ends by zeroing the external field
     // run at once where the reference does something between two iterations that the queue would skip, and bound the queue
     if ((global.cellsDeletedInfo && particle_step) || pending >= 1024) {
       flush();

@@ -138,6 +138,36 @@ struct Periodicity3D {
 
 // The driver-facing lattice: a recorder in front of hc_lattice.  The device object is created on first
 // use because drivers keep changing the description (periodicity, flags) after lattice->initialize().
+// What the setExternalVector calls on a lattice add up to: one force for the whole domain plus a few boxes with their own
+// (cases/kolmogorovFlow/kolmogorovFlow.cpp:136-140).  The library evaluates it inside its kernels (hcl_set_body_force,
+// hcl_set_body_force_regions); no per-node force field exists on the host.
+template <typename U>
+struct ExternalForce {
+  struct Region { Box3D box; std::array<U, 3> f; };
+  std::array<U, 3> base{{U(0), U(0), U(0)}};
+  std::vector<Region> regions;
+  static bool same_box(const Box3D &a, const Box3D &b) { return a.x0 == b.x0 && a.x1 == b.x1 && a.y0 == b.y0 && a.y1 == b.y1 && a.z0 == b.z0 && a.z1 == b.z1; }
+  bool operator==(const ExternalForce &o) const {
+    if (base != o.base || regions.size() != o.regions.size()) return false;
+    for (size_t k = 0; k < regions.size(); k++) if (!same_box(regions[k].box, o.regions[k].box) || regions[k].f != o.regions[k].f) return false;
+    return true;
+  }
+  void set(const Box3D &box, const Box3D &whole, const std::array<U, 3> &F) {
+    if (box.x0 <= whole.x0 && box.x1 >= whole.x1 && box.y0 <= whole.y0 && box.y1 >= whole.y1 && box.z0 <= whole.z0 && box.z1 >= whole.z1) { base = F; regions.clear(); return; }
+    for (size_t k = 0; k < regions.size(); k++) if (same_box(regions[k].box, box)) { regions.erase(regions.begin() + (long)k); break; }   // written again: it now overrides the others
+    if (regions.size() == HC_MAX_FORCE_REGIONS) {
+      std::cerr << "(HemoCell) (GPU backend) setExternalVector: more than " << HC_MAX_FORCE_REGIONS << " sub-domains with their own force" << std::endl;
+      std::exit(1);
+    }
+    regions.push_back({box, F});
+  }
+  std::array<U, 3> at(plint x, plint y, plint z) const {
+    std::array<U, 3> f = base;
+    for (const Region &r : regions) if (x >= r.box.x0 && x <= r.box.x1 && y >= r.box.y0 && y <= r.box.y1 && z >= r.box.z0 && z <= r.box.z1) f = r.f;
+    return f;
+  }
+};
+
 template <typename U, template <typename> class D>
 class MultiBlockLattice3D {
  public:
@@ -159,7 +189,18 @@ class MultiBlockLattice3D {
   // reference's block distribution does along one axis.  The driver keeps describing the global lattice.
   hc_lattice *device() {
     if (before_access) before_access();   // iterations the facade has queued run first (hemo::HemoCell::flush)
+    sync_force();
     return device_now();
+  }
+  // The external force as the reference's field would hold it now: HemoCell::iterate() ends by zeroing it
+  // (core/hemoCell.cpp:369-371) and drivers write it again around every iteration.
+  ExternalForce<U> external_now() const { return force_cleared ? ExternalForce<U>() : applied; }
+  // make it the one the device steps with; iterations queued under the previous one run first
+  void sync_force() {
+    const ExternalForce<U> e = external_now();
+    if (e == active) return;
+    if (before_access) before_access();
+    active = e; dirty_force = true;
   }
   hc_lattice *device_now() {
     if (dev && !dirty_layout) { if (dirty_force) push_force(); return dev; }
@@ -188,7 +229,19 @@ class MultiBlockLattice3D {
     push_force();
     return dev;
   }
-  void push_force() { double f[3] = {body[0], body[1], body[2]}; hc_check(hcl_set_body_force(dev, f), "hcl_set_body_force"); dirty_force = false; }
+  void push_force() {
+    double f[3] = {active.base[0], active.base[1], active.base[2]};
+    hc_check(hcl_set_body_force(dev, f), "hcl_set_body_force");
+    int boxes[6 * HC_MAX_FORCE_REGIONS]; double rf[3 * HC_MAX_FORCE_REGIONS];
+    for (size_t k = 0; k < active.regions.size(); k++) {
+      const Box3D &b = active.regions[k].box;
+      const plint v[6] = {b.x0, b.x1, b.y0, b.y1, b.z0, b.z1};
+      for (int i = 0; i < 6; i++) boxes[6 * k + i] = (int)v[i];
+      for (int d = 0; d < 3; d++) rf[3 * k + d] = active.regions[k].f[d];
+    }
+    hc_check(hcl_set_body_force_regions(dev, (int)active.regions.size(), boxes, rf), "hcl_set_body_force_regions");
+    dirty_force = false;
+  }
   void mark_stepped() { stepped = true; }
 
   // velocity-wall classes (mask values 3..6), helper/hemocellInit.hh:71-86
@@ -212,7 +265,8 @@ class MultiBlockLattice3D {
   U bb_rho = 1;
   Periodicity3D per;
   U eq_rho = 1; U eq_u[3] = {0, 0, 0};
-  U body[3] = {0, 0, 0};
+  ExternalForce<U> applied, active;   // written by the driver since the field was last zeroed / what the device steps with
+  bool force_cleared = false;         // an iterate() has zeroed the field and nothing was written since
   std::function<void()> before_access;
   bool dirty_layout = true, dirty_force = true, stepped = false, cells_bound = false;
   hc_lattice *dev = nullptr;
@@ -244,11 +298,9 @@ void defineDynamics(MultiBlockLattice3D<U, D> &lattice, Box3D box, Dynamics<U, D
 
 // setExternalVector(lattice, bbox, forceBeginsAt, F)   (core/hemoCell.cpp:369-371, examples/pipeflow/pipeflow.cpp:144-146)
 template <typename U, template <typename> class D>
-void setExternalVector(MultiBlockLattice3D<U, D> &lattice, Box3D, int, Array<U, 3> F) {
-  if (F[0] != lattice.body[0] || F[1] != lattice.body[1] || F[2] != lattice.body[2]) {
-    if (lattice.before_access) lattice.before_access();   // queued iterations still belong to the old force
-    lattice.body[0] = F[0]; lattice.body[1] = F[1]; lattice.body[2] = F[2]; lattice.dirty_force = true;
-  }
+void setExternalVector(MultiBlockLattice3D<U, D> &lattice, Box3D box, int, Array<U, 3> F) {
+  if (lattice.force_cleared) { lattice.applied = ExternalForce<U>(); lattice.force_cleared = false; }
+  lattice.applied.set(box, lattice.getBoundingBox(), std::array<U, 3>{{F[0], F[1], F[2]}});   // reaches the device at the next step or look (sync_force)
 }
 
 // ---- boundary-condition names of examples/stretchCell/stretchCell.cpp:74-79 and helper/hemocellInit.hh:71-86.

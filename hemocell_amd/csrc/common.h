@@ -79,6 +79,20 @@ int stat_finish(const double *d_partial, double out[3], long *n, double *h_pinne
 
 }  // namespace hc
 
+namespace hc {
+// setExternalVector on part of the domain (cases/kolmogorovFlow/kolmogorovFlow.cpp:136-140): up to HC_MAX_FORCE_REGIONS boxes
+// (inclusive global node ranges) whose nodes carry f instead of the uniform body force; a later box overrides an earlier one
+struct BodyRegions { int n; int box[HC_MAX_FORCE_REGIONS][6]; double f[HC_MAX_FORCE_REGIONS][3]; };
+#ifdef __HIPCC__
+__device__ __forceinline__ void region_force(const BodyRegions &r, int xg, int y, int z, double &bx, double &by, double &bz) {
+  for (int k = 0; k < r.n; k++) {
+    const int *b = r.box[k];
+    if (xg >= b[0] && xg <= b[1] && y >= b[2] && y <= b[3] && z >= b[4] && z <= b[5]) { bx = r.f[k][0]; by = r.f[k][1]; bz = r.f[k][2]; }
+  }
+}
+#endif
+}  // namespace hc
+
 struct hc_lattice {
   int nx, ny, nz;        // local bulk dims
   int periodic[3];       // global periodicity
@@ -107,6 +121,7 @@ struct hc_lattice {
   uint8_t *mask;         // [npad]
   std::vector<uint8_t> hmask;  // host copy (cell placement tests against it)
   double body[3];
+  hc::BodyRegions regions;   // boxes with their own body force (hcl_set_body_force_regions), global node coordinates
   double wall_u[4][3];   // velocities of the moving-wall mask classes 3..6
   // active-node map of the collide kernel: per padded plane and row, the z-span that holds every node
   // which is not an inert solid, flattened so that a launch only creates threads for those spans

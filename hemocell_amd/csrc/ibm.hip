@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void ibm_spread_kernel(LatView v, long n, cons
 // interpolate: v = sum_j w_j * (j/rho + F/2)(node_j) on the post-stream state
 struct PopView {
   const double *f; const double *F; double bx, by, bz; long qs;   // qs: population stride
+  hc::BodyRegions reg;
 };
 
 __device__ __forceinline__ void node_velocity(const LatView &v, const PopView &pv, int lx, int ly, int lz, long node, double u[3]) {
@@ -77,9 +78,15 @@ __device__ __forceinline__ void node_velocity(const LatView &v, const PopView &p
   M(18, 0, 1, -1)
 #undef M
   const double invRho = 1.0 / (1.0 + r);
-  u[0] = jx * invRho + (pv.bx + pv.F[node]) / 2.0;
-  u[1] = jy * invRho + (pv.by + pv.F[v.npad + node]) / 2.0;
-  u[2] = jz * invRho + (pv.bz + pv.F[2 * v.npad + node]) / 2.0;
+  double bx = pv.bx, by = pv.by, bz = pv.bz;
+  if (pv.reg.n) {   // a halo plane of a slab, or the wrapped image, is the global node next door
+    int xg = v.x0 + lx;
+    if (xg < 0) xg += v.nx_global; else if (xg >= v.nx_global) xg -= v.nx_global;
+    region_force(pv.reg, xg, ly, lz, bx, by, bz);
+  }
+  u[0] = jx * invRho + (bx + pv.F[node]) / 2.0;
+  u[1] = jy * invRho + (by + pv.F[v.npad + node]) / 2.0;
+  u[2] = jz * invRho + (bz + pv.F[2 * v.npad + node]) / 2.0;
 }
 
 __global__ __launch_bounds__(256) void ibm_interpolate_kernel(LatView v, PopView pv, long n, const double *px, const double *py,
@@ -505,7 +512,7 @@ int hcp_interpolate(hc_cells *C) {
   const hc_lattice *L = C->L;
   const LatView v = make_view(L);
   // state after hcl_step_end: f[cur] holds the populations just written, force[(fcur+2)%3] the force they were collided with
-  PopView pv{L->f[L->cur], L->force[(L->fcur + 2) % 3], L->body[0], L->body[1], L->body[2], (long)L->qstride};
+  PopView pv{L->f[L->cur], L->force[(L->fcur + 2) % 3], L->body[0], L->body[1], L->body[2], (long)L->qstride, L->regions};
   for (int t = 0; t < C->ntypes; t++) {
     const long n = C->ncells[t] * C->types[t]->host.nv, f = C->first[t];
     if (n == 0) continue;
@@ -536,7 +543,7 @@ int hcp_interpolate_cells(hc_cells *C, int type, const int *slots, int n) {
   hc::ProfScope prof(hc::PK_INTERP);
   const hc_lattice *L = C->L;
   const LatView v = make_view(L);
-  PopView pv{L->f[L->cur], L->force[(L->fcur + 2) % 3], L->body[0], L->body[1], L->body[2], (long)L->qstride};
+  PopView pv{L->f[L->cur], L->force[(L->fcur + 2) % 3], L->body[0], L->body[1], L->body[2], (long)L->qstride, L->regions};
   const long f = C->first[type];
   const int nv = C->types[type]->host.nv;
   hipLaunchKernelGGL(ibm_interpolate_cell_kernel, dim3((unsigned)n), dim3(nv > 128 ? 256 : 128), 0, hc::stream(), v, pv, nv,

@@ -45,7 +45,15 @@ struct LatArgs {
   int ibm;               // 0: no membrane cells are bound to this lattice -> the IBM force buffers are not touched
   const uint8_t *dirty_in, *dirty_zero; uint8_t epoch_in, epoch_zero;
   double wall_u[4][3];   // moving-wall classes 3..6
+  int x0, nx_global;     // global x of plane 0 (body-force regions are given in global coordinates)
+  BodyRegions reg;
 };
+
+// uniform body force, or that of the last region holding the node
+__device__ __forceinline__ void body_at(const LatArgs &a, int x, int y, int z, double &bx, double &by, double &bz) {
+  bx = a.bx; by = a.by; bz = a.bz;
+  if (a.reg.n) region_force(a.reg, a.x0 + x, y, z, bx, by, bz);
+}
 
 struct Nbr {  // element offsets to the -1 / +1 neighbour along each axis, and validity
   long xm, xp;
@@ -165,6 +173,7 @@ __device__ __forceinline__ void collide_guo(double f[HC_Q], double Fx, double Fy
 #undef M
 }
 
+template <bool REGIONS>
 __global__ __launch_bounds__(256) void collide_stream_kernel(LatArgs a) {
   // thread -> (y,z) through the active-span map of this plane: consecutive threads walk the spans of
   // consecutive rows, so every lane of every wave (except the last of a plane) has a live node
@@ -202,9 +211,11 @@ __global__ __launch_bounds__(256) void collide_stream_kernel(LatArgs a) {
 #undef M
     }
   } else {
-    double Fx = a.bx, Fy = a.by, Fz = a.bz;
+    double bx = a.bx, by = a.by, bz = a.bz;
+    if (REGIONS) region_force(a.reg, a.x0 + x, y, z, bx, by, bz);
+    double Fx = bx, Fy = by, Fz = bz;
     if (a.ibm && a.dirty_in[node >> 4] == a.epoch_in) {   // x + 0.0 == x, so skipping untouched groups changes no bits
-      Fx = a.bx + a.Fin[node]; Fy = a.by + a.Fin[a.npad + node]; Fz = a.bz + a.Fin[2 * a.npad + node];
+      Fx = bx + a.Fin[node]; Fy = by + a.Fin[a.npad + node]; Fz = bz + a.Fin[2 * a.npad + node];
     }
     collide_guo(f, Fx, Fy, Fz, a.omega);
   }
@@ -289,9 +300,11 @@ __global__ void rho_u_kernel(LatArgs a, double *rho, double *u) {
   const double invRho = 1.0 / (1.0 + rhoBar);
   const long o = (long)x * a.plane + p;
   rho[o] = 1.0 + rhoBar;
-  u[3 * o] = j0 * invRho + (a.bx + a.Fin[node]) / 2.0;
-  u[3 * o + 1] = j1 * invRho + (a.by + a.Fin[a.npad + node]) / 2.0;
-  u[3 * o + 2] = j2 * invRho + (a.bz + a.Fin[2 * a.npad + node]) / 2.0;
+  double bx, by, bz;
+  body_at(a, x, y, z, bx, by, bz);
+  u[3 * o] = j0 * invRho + (bx + a.Fin[node]) / 2.0;
+  u[3 * o + 1] = j1 * invRho + (by + a.Fin[a.npad + node]) / 2.0;
+  u[3 * o + 2] = j2 * invRho + (bz + a.Fin[2 * a.npad + node]) / 2.0;
 }
 
 // Off-equilibrium part of the momentum-flux tensor, as Palabos' momentTemplates::compute_rhoBar_j_PiNeq forms it from the
@@ -354,11 +367,13 @@ __global__ __launch_bounds__(256) void fluid_stats_kernel(LatArgs a, int what, d
       continue;
     }
     if (a.mask[node] != 0) continue;
-    double Fx = a.bx, Fy = a.by, Fz = a.bz;
-    if (a.ibm) { Fx = a.bx + a.Fin[node]; Fy = a.by + a.Fin[a.npad + node]; Fz = a.bz + a.Fin[2 * a.npad + node]; }
+    const int y = p / a.nz, z = p - y * a.nz;
+    double bx, by, bz;
+    body_at(a, x, y, z, bx, by, bz);
+    double Fx = bx, Fy = by, Fz = bz;
+    if (a.ibm) { Fx = bx + a.Fin[node]; Fy = by + a.Fin[a.npad + node]; Fz = bz + a.Fin[2 * a.npad + node]; }
     double v0 = Fx, v1 = Fy, v2 = Fz;
     if (what == 0) {
-      const int y = p / a.nz, z = p - y * a.nz;
       const Nbr n = neighbours(a, x, y, z);
       double f[HC_Q];
       pull(a.fin, a.qs, node, n, f);
@@ -410,6 +425,7 @@ LatArgs make_args(const hc_lattice *L) {
   a.wrap_x = (L->n_slabs == 1 && L->periodic[0]) ? 1 : 0;
   a.per_y = L->periodic[1]; a.per_z = L->periodic[2];
   a.omega = L->omega; a.bx = L->body[0]; a.by = L->body[1]; a.bz = L->body[2];
+  a.x0 = L->x0; a.nx_global = L->nx_global; a.reg = L->regions;
   a.row_z0 = L->row_z0; a.row_cum = L->row_cum; a.blk_row = L->blk_row; a.nblk = L->nblk;
   a.ibm = L->ibm;
   a.dirty_in = L->fdirty[L->fcur]; a.dirty_zero = L->fdirty[fprev]; a.epoch_in = L->fepoch[L->fcur]; a.epoch_zero = L->fepoch[fprev];
@@ -498,7 +514,8 @@ int launch_collide(hc_lattice *L, int x_begin, int nplanes) {
   if (nplanes <= 0) return HC_OK;
   LatArgs a = make_args(L);
   a.x_begin = x_begin;
-  hipLaunchKernelGGL(collide_stream_kernel, dim3((unsigned)((L->max_active + 255) / 256), (unsigned)nplanes, 1), dim3(256), 0, hc::stream(), a);
+  if (L->regions.n) hipLaunchKernelGGL(collide_stream_kernel<true>, dim3((unsigned)((L->max_active + 255) / 256), (unsigned)nplanes, 1), dim3(256), 0, hc::stream(), a);
+  else hipLaunchKernelGGL(collide_stream_kernel<false>, dim3((unsigned)((L->max_active + 255) / 256), (unsigned)nplanes, 1), dim3(256), 0, hc::stream(), a);
   HC_HIP(hipGetLastError());
   return HC_OK;
 }
@@ -541,6 +558,7 @@ int hcl_create(hc_lattice **out, int nx, int ny, int nz, const int periodic[3], 
   L->qstride = L->npad + 16 * 129;
   L->cur = 0; L->fcur = 0; L->ibm = 0;
   L->body[0] = L->body[1] = L->body[2] = 0.0;
+  L->regions.n = 0;
   for (int c = 0; c < 4; c++) for (int d = 0; d < 3; d++) L->wall_u[c][d] = 0.0;
   L->scratch = nullptr; L->scratch_doubles = 0;
   L->f[0] = L->f[1] = nullptr; L->mask = nullptr;
@@ -676,6 +694,19 @@ int hcl_set_wall_velocity(hc_lattice *L, int wall_class, const double u[3]) {
 int hcl_set_body_force(hc_lattice *L, const double F[3]) {
   HC_REQUIRE(L && F, "hcl_set_body_force: null pointer");
   for (int d = 0; d < 3; d++) L->body[d] = F[d];
+  return HC_OK;
+}
+
+int hcl_set_body_force_regions(hc_lattice *L, int n, const int *boxes, const double *forces) {
+  HC_REQUIRE(L && n >= 0 && (n == 0 || (boxes && forces)), "hcl_set_body_force_regions: bad arguments");
+  HC_REQUIRE(n <= HC_MAX_FORCE_REGIONS, "hcl_set_body_force_regions: more than HC_MAX_FORCE_REGIONS boxes");
+  for (int k = 0; k < n; k++) {
+    const int *b = boxes + 6 * k;
+    HC_REQUIRE(b[0] <= b[1] && b[2] <= b[3] && b[4] <= b[5], "hcl_set_body_force_regions: empty box");
+    for (int i = 0; i < 6; i++) L->regions.box[k][i] = b[i];
+    for (int d = 0; d < 3; d++) L->regions.f[k][d] = forces[3 * k + d];
+  }
+  L->regions.n = n;
   return HC_OK;
 }
 

@@ -89,6 +89,14 @@ class Lattice:
         ff = np.array(F, dtype=np.float64)
         check(self.lib.hcl_set_body_force(self.ptr, dptr(ff)))
 
+    def setExternalVectorBoxes(self, boxes, forces):
+        """setExternalVector on sub-domains (cases/kolmogorovFlow/kolmogorovFlow.cpp:136-140): inclusive global node boxes
+        (x0, x1, y0, y1, z0, z1), later ones override earlier ones; an empty list removes them"""
+        bb = np.ascontiguousarray(boxes, dtype=np.int32).reshape(-1, 6)
+        ff = np.ascontiguousarray(forces, dtype=np.float64).reshape(-1, 3)
+        assert len(bb) == len(ff)
+        check(self.lib.hcl_set_body_force_regions(self.ptr, len(bb), bb.ctypes.data_as(C.POINTER(C.c_int)), dptr(ff)))
+
     def setBoundaryVelocity(self, wall_class, u):
         """velocity of the nodes whose mask value is wall_class (3..6)"""
         uu = np.array(u, dtype=np.float64)

@@ -125,6 +125,12 @@ int hcl_init_equilibrium(hc_lattice *L, double rho, const double u[3]);
 /* setExternalVector(lattice, bbox, forceBeginsAt, F) (core/hemoCell.cpp:369-371, examples/pipeflow/pipeflow.cpp:144-146):
  * the uniform driving force; the per-node IBM force is kept separately and zeroed by the collide kernel */
 int hcl_set_body_force(hc_lattice *L, const double F[3]);
+/* setExternalVector on PART of the domain (cases/kolmogorovFlow/kolmogorovFlow.cpp:136-140: +F on one half of the box, -F on
+ * the other): n <= HC_MAX_FORCE_REGIONS boxes, boxes[k] = {x0, x1, y0, y1, z0, z1} inclusive GLOBAL node ranges, whose nodes
+ * carry forces[k] instead of the uniform body force; where boxes overlap the later one holds, as with consecutive
+ * setExternalVector calls.  n = 0 removes them.  Evaluated inside the kernels from these few numbers: no force field in HBM. */
+#define HC_MAX_FORCE_REGIONS 4
+int hcl_set_body_force_regions(hc_lattice *L, int n, const int *boxes, const double *forces);
 /* setBoundaryVelocity(lattice, box, u) on nodes flagged by setVelocityConditionOnBlockBoundaries
  * (helper/hemocellInit.hh:71-86): mask classes 3..6 are moving no-slip walls with velocity u (full-way
  * bounce-back + Ladd momentum term; stand-in for Palabos' regularised boundary, which is not available) */

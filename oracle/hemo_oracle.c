@@ -79,6 +79,16 @@ void orc_lattice_set_force_uniform(orc_lattice *L, const double F[3]) {
   for (long k = 0; k < n; k++) { L->force[3 * k] = F[0]; L->force[3 * k + 1] = F[1]; L->force[3 * k + 2] = F[2]; }
 }
 
+/* the same call with a sub-domain (cases/kolmogorovFlow/kolmogorovFlow.cpp:136-140); box = inclusive {x0,x1,y0,y1,z0,z1} */
+void orc_lattice_set_force_box(orc_lattice *L, const int box[6], const double F[3]) {
+  for (int x = box[0] < 0 ? 0 : box[0]; x <= box[1] && x < L->nx; x++)
+    for (int y = box[2] < 0 ? 0 : box[2]; y <= box[3] && y < L->ny; y++)
+      for (int z = box[4] < 0 ? 0 : box[4]; z <= box[5] && z < L->nz; z++) {
+        long k = ((long)x * L->ny + y) * L->nz + z;
+        L->force[3 * k] = F[0]; L->force[3 * k + 1] = F[1]; L->force[3 * k + 2] = F[2];
+      }
+}
+
 static inline void moments(const double *f, double *rhoBar, double j[3]) {
   double r = 0, jx = 0, jy = 0, jz = 0;
   for (int i = 0; i < ORC_Q; i++) {
@@ -1153,5 +1163,6 @@ void orc_sim_iterate(orc_sim *S) {
   orc_sim_advance(S);                                           /* :342 */
   orc_sim_mechanics(S, 0);                                      /* :345 */
   orc_lattice_set_force_uniform(S->L, S->body_force);           /* :369-371 + driver */
+  for (int r = 0; r < S->n_regions; r++) orc_lattice_set_force_box(S->L, S->region_box[r], S->region_force[r]);
   S->iter++;                                                    /* :374 */
 }

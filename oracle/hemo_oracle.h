@@ -42,6 +42,7 @@ void orc_lattice_destroy(orc_lattice *L);
 void orc_lattice_set_mask(orc_lattice *L, const unsigned char *mask);
 void orc_lattice_init_equilibrium(orc_lattice *L, double rho, const double u[3]);
 void orc_lattice_set_force_uniform(orc_lattice *L, const double F[3]);
+void orc_lattice_set_force_box(orc_lattice *L, const int box[6], const double F[3]);
 void orc_collide_stream(orc_lattice *L);
 /* rho and u = j/rho + F/2 of the current (post-stream) populations */
 void orc_node_rho_u(const orc_lattice *L, long node, double *rho, double u[3]);
@@ -141,6 +142,9 @@ typedef struct orc_sim {
   int deletion_mode;
   unsigned char *dead;      /* [np] 1 = this particle was removed (its record stays in place so that cell-major indexing holds) */
   long particles_deleted;
+  /* setExternalVector on sub-boxes, re-applied by the driver around every iterate like the uniform force
+   * (cases/kolmogorovFlow/kolmogorovFlow.cpp:136-140): inclusive node ranges {x0,x1,y0,y1,z0,z1}, applied in order */
+  int n_regions; int region_box[4][6]; double region_force[4][3];
 } orc_sim;
 
 orc_sim *orc_sim_create(orc_lattice *L, const orc_params *P);

@@ -63,7 +63,8 @@ class Sim(C.Structure):
                 ("iter", C.c_long), ("cells_deleted", C.c_long), ("body_force", C.c_double * 3),
                 ("rep_enabled", C.c_int), ("rep_timescale", C.c_int), ("rep_const", C.c_double), ("rep_cutoff", C.c_double),
                 ("brep_enabled", C.c_int), ("brep_timescale", C.c_int), ("brep_const", C.c_double), ("brep_cutoff", C.c_double),
-                ("deletion_mode", C.c_int), ("dead", C.c_void_p), ("particles_deleted", C.c_long)]
+                ("deletion_mode", C.c_int), ("dead", C.c_void_p), ("particles_deleted", C.c_long),
+                ("n_regions", C.c_int), ("region_box", (C.c_int * 6) * 4), ("region_force", (C.c_double * 3) * 4)]
 
 
 def build():
@@ -82,6 +83,7 @@ def load():
         "orc_lattice_set_mask": (None, [LP, C.c_void_p]),
         "orc_lattice_init_equilibrium": (None, [LP, C.c_double, c_double_p]),
         "orc_lattice_set_force_uniform": (None, [LP, c_double_p]),
+        "orc_lattice_set_force_box": (None, [LP, C.POINTER(C.c_int), c_double_p]),
         "orc_collide_stream": (None, [LP]),
         "orc_lattice_set_threads": (None, [LP, C.c_int]),
         "orc_lattice_set_wall_velocity": (None, [LP, C.c_int, c_double_p]),
@@ -148,6 +150,11 @@ class OracleLattice:
     def set_force_uniform(self, F):
         ff = np.array(F, dtype=np.float64)
         self.lib.orc_lattice_set_force_uniform(self.ptr, dptr(ff))
+
+    def set_force_box(self, box, F):
+        """setExternalVector on a sub-domain; box = inclusive (x0, x1, y0, y1, z0, z1)"""
+        bb = (C.c_int * 6)(*[int(b) for b in box]); ff = np.array(F, dtype=np.float64)
+        self.lib.orc_lattice_set_force_box(self.ptr, bb, dptr(ff))
 
     def set_threads(self, n):
         self.lib.orc_lattice_set_threads(self.ptr, n)

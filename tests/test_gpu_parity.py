@@ -277,16 +277,20 @@ def test_ibm_oversized_cells_take_the_fallback_paths(orc, gpu, scale, which):
     Lo.destroy(); Lg.destroy()
 
 
-@pytest.mark.parametrize("case", ["pipe_rbc", "pipe_rbc_plt_cadence", "box_periodic", "pipe_rbc_plt_cadence_beside"])
+@pytest.mark.parametrize("case", ["pipe_rbc", "pipe_rbc_plt_cadence", "box_periodic", "pipe_rbc_plt_cadence_beside", "box_kolmogorov"])
 def test_iterate_trajectories_vs_oracle(orc, gpu, case):
     """HemoCell::iterate for N steps: fluid populations and vertex positions within 1e-6 relative of the
     oracle (north_star tolerance); in practice ~1e-12 (only the atomic spread order differs).
     _beside: no deletion checks inside the call, so that hc_iterate puts advance, mechanics and the next spread on
     the side stream beside the collide between velocity updates (the schedule bench.py measures)"""
-    if case == "box_periodic":
+    boxes = None
+    if case in ("box_periodic", "box_kolmogorov"):
         nx, ny, nz = 32, 32, 32
         periodic = (1, 1, 1); mask = np.zeros((nx, ny, nz), np.uint8); k_m, k_p, plt = 1, 1, False
         F = (1e-6, 2e-6, -1e-6)
+        if case == "box_kolmogorov":   # cases/kolmogorovFlow/kolmogorovFlow.cpp:86-90,136-140: +F on one half of the box, -F on the other
+            F = (0.0, 0.0, 0.0)
+            boxes = [((0, nx - 1, 0, (ny - 1) // 2, 0, nz - 1), (2e-5, 0.0, 0.0)), ((0, nx - 1, (ny - 1) // 2 + 1, ny - 1, 0, nz - 1), (-2e-5, 0.0, 0.0))]
     else:
         nx, ny, nz = 48, 34, 34
         mask, R = gpu.pipe_mask(nx, ny, nz); periodic = (1, 0, 0)
@@ -300,6 +304,15 @@ def test_iterate_trajectories_vs_oracle(orc, gpu, case):
         assert _add_both(orc, So, hg, 1, (45.0, 20.0, 13.0), (0, 0, 0))
     Lo.set_force_uniform(F); Lg.setExternalVector(F)
     So.contents.body_force[0], So.contents.body_force[1], So.contents.body_force[2] = F
+    if boxes:
+        Lg.setExternalVectorBoxes([b for b, _ in boxes], [f for _, f in boxes])
+        So.contents.n_regions = len(boxes)
+        for r, (b, f) in enumerate(boxes):
+            Lo.set_force_box(b, f)
+            for i in range(6):
+                So.contents.region_box[r][i] = b[i]
+            for d in range(3):
+                So.contents.region_force[r][d] = f[d]
     Lo.set_threads(8)
     orc.orc_sim_mechanics(So, 1); hg.cellfields.applyConstitutiveModel(0, True)
     nsteps = 60
@@ -325,6 +338,17 @@ def test_iterate_trajectories_vs_oracle(orc, gpu, case):
     fo, fg = Lo.f[fluid], Lg.populations()[fluid]
     assert np.abs(fg - fo).max() <= 1e-6 * np.abs(fo).max()
     assert np.abs(hg.cellfields.forces - f_o).max() <= 1e-6 * np.abs(f_o).max()
+    if boxes:   # the two halves stream against each other; Cell::computeVelocity carries the half's own F / 2
+        import ctypes as C
+        rho, u = Lg.rho_u()
+        ux = u[:, 0].reshape(nx, ny, nz)
+        assert ux[:, 2:14].min() > 0 and ux[:, 18:30].max() < 0
+        uo = np.zeros(ny)
+        for y in range(ny):
+            r_, u_ = C.c_double(), np.zeros(3)
+            orc.orc_node_rho_u(Lo.ptr, ((5 * ny) + y) * nz + 7, C.byref(r_), gpu.dptr(u_))
+            uo[y] = u_[0]
+        assert np.abs(ux[5, :, 7] - uo).max() <= 1e-9 * np.abs(uo).max()
     Lo.destroy(); Lg.destroy()
 
 

@@ -73,13 +73,15 @@ struct Array : std::array<U, N> {
 
 // ------------------------------------------------------------------ config/logfile.h
 struct Logger {
-  bool to_stdout; std::ofstream file;
+  bool to_stdout; std::ofstream file; Logger *sink = nullptr;   // hlogfile writes into hlog's file (config/logfile.h:61-76)
+  string filename;
   explicit Logger(bool s) : to_stdout(s) {}
-  template <typename V> Logger &operator<<(const V &v) { if (to_stdout) std::cout << v; if (file.is_open()) file << v; return *this; }
-  Logger &operator<<(std::ostream &(*f)(std::ostream &)) { if (to_stdout) std::cout << f; if (file.is_open()) file << f; return *this; }
+  std::ofstream &out() { return sink ? sink->file : file; }
+  template <typename V> Logger &operator<<(const V &v) { if (to_stdout) std::cout << v; if (out().is_open()) out() << v; return *this; }
+  Logger &operator<<(std::ostream &(*f)(std::ostream &)) { if (to_stdout) std::cout << f; if (out().is_open()) out() << f; return *this; }
 };
 inline Logger &hlog_instance() { static Logger l(true); return l; }
-inline Logger &hlogfile_instance() { static Logger l(false); return l; }
+inline Logger &hlogfile_instance() { static Logger l(false); if (!l.sink) l.sink = &hlog_instance(); return l; }
 #define hlog hemo::hlog_instance()
 #define hlogfile hemo::hlogfile_instance()
 
@@ -142,6 +144,13 @@ class Config {
   }
   XMLElement operator[](const string &name) const { return XMLElement(root)[name]; }
   bool checkpointed = false;
+  // <Checkpoint><General><name> of a checkpoint.xml (core/hemoCellFields.cpp:244-248); empty if absent
+  string checkpointGeneral(const string &name) const {
+    XMLNode *c = doc->child("Checkpoint"), *g = c ? c->child("General") : nullptr, *n = g ? g->child(name) : nullptr;
+    if (!n) return string();
+    const size_t a = n->text.find_first_not_of(" \t\r\n"), b = n->text.find_last_not_of(" \t\r\n");
+    return a == string::npos ? string() : n->text.substr(a, b - a + 1);
+  }
  private:
   std::unique_ptr<XMLNode> doc; XMLNode *root = nullptr;
 };
@@ -208,6 +217,7 @@ struct ProfilerView {
 struct Global {   // config/config.h:80-96 (ConfigValues) plus this rank's place in the run
   ProfilerView statistics; bool cellsDeletedInfo = false; bool hemoCellInitialized = false;
   int rank = 0, world = 1;
+  string checkpointDirectory;   // config/config.h:84, set by loadDirectories
 };
 static Global global;
 
@@ -445,18 +455,52 @@ class HemoCell {
     if (global.world == 1) hc_check(hc_init(0), "hc_init");
     cfg = new Config(configFileName);
     configFile = configFileName;
-    try { outDir = (*cfg)["parameters"]["outputDirectory"].read<string>(); } catch (std::invalid_argument &) { outDir = "tmp"; }
     try { global.cellsDeletedInfo = (*cfg)["verbose"]["cellsDeletedInfo"].read<int>() != 0; } catch (std::invalid_argument &) {}   // config/config.cpp:180
-    if (global.rank == 0) {
-      mkdir(outDir.c_str(), 0755); mkdir((outDir + "/log").c_str(), 0755); mkdir((outDir + "/csv").c_str(), 0755);
-      hlog_instance().file.open((outDir + "/log/logfile").c_str());
-      hlogfile_instance().file.open((outDir + "/log/logfile.detail").c_str());
-    } else hlog_instance().to_stdout = false;   // the log is rank 0's (config/logfile.h)
-    hc_comm_barrier();
+    if (global.rank != 0) hlog_instance().to_stdout = false;   // the log is rank 0's (config/logfile.h)
+    loadDirectories(true);
     hlog << "(HemoCell) (Config) reading " << configFileName << endl;
     if (global.world > 1) hlog << "(HemoCell) (GPU backend) " << global.world << " atomic-blocks: one x-slab per rank and GPU, " << (tr == HC_TRANSPORT_RCCL ? "RCCL point-to-point" : "host-staged (ranks share a GPU)") << " neighbour exchange" << endl;
   }
   ~HemoCell() { flush(); hc_synchronize(); delete cellfields; delete lattice; delete cfg; hc_comm_finalize(); global.hemoCellInitialized = false; }   // core/hemoCell.cpp:97-127: the facade owns the driver's lattice
+
+  // config/config.cpp:88-174 (loadDirectories): <parameters><outputDirectory> (default ./tmp) gets _0, _1, ... appended when it
+  // exists already; the log goes to <logDirectory>/<logFile> below it (default log/logfile), with .0, .1, ... appended when
+  // that exists; checkpoints to <checkpointDirectory> below it.  Rank 0 looks and creates, the others are told.
+  static bool path_exists(const string &p) { struct stat st; return ::stat(p.c_str(), &st) == 0; }
+  static void mkpath(const string &p) { for (size_t i = 1; i <= p.size(); i++) if (i == p.size() || p[i] == '/') ::mkdir(p.substr(0, i).c_str(), 0777); }
+  void loadDirectories(bool edit_out_dir) {
+    char names[2][1024]; std::memset(names, 0, sizeof(names));
+    if (global.rank == 0) {
+      if (edit_out_dir) {
+        try {
+          outDir = (*cfg)["parameters"]["outputDirectory"].read<string>();
+          while (outDir.size() > 1 && outDir[outDir.size() - 1] == '/') outDir.pop_back();
+          if (outDir[0] != '/') outDir = "./" + outDir;
+        } catch (std::invalid_argument &) { outDir = "./tmp"; }
+        if (path_exists(outDir))
+          for (int i = 0;; i++) if (!path_exists(outDir + "_" + std::to_string(i))) { outDir += "_" + std::to_string(i); break; }
+      }
+      mkpath(outDir + "/hdf5");
+      string logDir = "log", logName = "logfile";
+      try { logDir = (*cfg)["parameters"]["logDirectory"].read<string>(); } catch (std::invalid_argument &) {}
+      try { logName = (*cfg)["parameters"]["logFile"].read<string>(); } catch (std::invalid_argument &) {}
+      mkpath(outDir + "/" + logDir);
+      string file = outDir + "/" + logDir + "/" + logName;
+      if (path_exists(file))
+        for (int i = 0;; i++) if (!path_exists(file + "." + std::to_string(i))) { file += "." + std::to_string(i); break; }
+      if (hlog_instance().file.is_open()) hlog_instance().file.close();
+      hlog_instance().filename = file;
+      hlog_instance().file.open(file.c_str());
+      if (!hlog_instance().file.is_open()) { std::cerr << "(HemoCell) (LogFile) Error opening logfile, exiting" << std::endl; std::exit(1); }
+      if (outDir.size() >= sizeof(names[0])) { std::cerr << "(HemoCell) output directory name too long" << std::endl; std::exit(1); }
+      std::strcpy(names[0], outDir.c_str());
+    }
+    hc_check(hc_comm_bcast(names, sizeof(names), 0), "hc_comm_bcast");
+    outDir = names[0];
+    string chk = "checkpoint";
+    try { chk = (*cfg)["parameters"]["checkpointDirectory"].read<string>(); } catch (std::invalid_argument &) {}
+    global.checkpointDirectory = outDir + "/" + chk + "/";
+  }
 
   void latticeEquilibrium(T rho, hemo::Array<T, 3> vel) { lattice->eq_rho = rho; for (int d = 0; d < 3; d++) lattice->eq_u[d] = vel[d]; lattice->dirty_layout = true; }
   void initializeCellfield() { cellfields = new HemoCellFields(*this); }
@@ -761,9 +805,9 @@ inline void HemoCell::loadParticles() {
 inline string checkpoint_file(const string &dir) { return dir + (global.world > 1 ? "/checkpoint." + std::to_string(global.rank) + ".bin" : string("/checkpoint.bin")); }
 
 inline void HemoCell::saveCheckPoint() {
-  const string dir = outDir + "/checkpoint";
+  string dir = global.checkpointDirectory; while (dir.size() > 1 && dir[dir.size() - 1] == '/') dir.pop_back();
   if (global.rank == 0) {
-    mkdir(dir.c_str(), 0755);
+    mkpath(dir);
     rename((dir + "/checkpoint.xml").c_str(), (dir + "/checkpoint.xml.old").c_str());
   }
   hc_comm_barrier();
@@ -786,7 +830,7 @@ inline void HemoCell::saveCheckPoint() {
   o.write((const char *)rec.data(), (std::streamsize)(rec.size() * sizeof(rec[0])));
   if (global.rank == 0) {
     std::ofstream x((dir + "/checkpoint.xml").c_str());
-    x << "<?xml version=\"1.0\" ?>\n<Checkpoint>\n<General><Iteration>" << iter << "</Iteration><OutDirectory>" << outDir << "</OutDirectory></General>\n";
+    x << "<?xml version=\"1.0\" ?>\n<Checkpoint>\n<General><Iteration>" << iter << "</Iteration><OutDirectory>" << outDir << "/</OutDirectory></General>\n";
     std::ifstream cfgin(configFile.c_str()); string line; bool first = true;
     while (std::getline(cfgin, line)) { if (first && line.find("<?xml") != string::npos) { first = false; continue; } x << line << "\n"; }
     x << "</Checkpoint>\n";
@@ -795,7 +839,13 @@ inline void HemoCell::saveCheckPoint() {
 }
 
 inline void HemoCell::loadCheckPoint() {
-  const string dir = outDir + "/checkpoint";
+  if (cfg->checkpointed) {   // core/hemoCellFields.cpp:244-250: continue in the directory the checkpoint names (the constructor has
+                             // opened a fresh one, as the reference's does)
+    string d = cfg->checkpointGeneral("OutDirectory");
+    while (d.size() > 1 && d[d.size() - 1] == '/') d.pop_back();
+    if (!d.empty()) { outDir = d; loadDirectories(false); }
+  } else hlog << "(HemoCell) (CellFields) loading checkpoint from non-checkpoint Config" << endl;
+  string dir = global.checkpointDirectory; while (dir.size() > 1 && dir[dir.size() - 1] == '/') dir.pop_back();
   std::ifstream in(checkpoint_file(dir).c_str(), std::ios::binary);
   if (!in.is_open()) { hlog << "(HemoCell) (loadCheckPoint) " << checkpoint_file(dir) << " not found" << endl; std::exit(1); }
   hc_lattice *d = lattice->device(); hc_cells *c = cellfields->device();
@@ -955,6 +1005,7 @@ inline void writeCellInfo_CSV(HemoCell &h) {
     for (int r = 0; r < global.world; r++) { const Row *b = gathered.data() + (size_t)r * (cap + 1); for (size_t k = 0; k < (size_t)b[0].v[0]; k++) all.push_back(b[1 + k]); }
     std::stable_sort(all.begin(), all.end(), [](const Row &a, const Row &b) { return a.v[6] < b.v[6]; });
   }
+  if (global.rank == 0) ::mkdir((h.outDir + "/csv").c_str(), 0777);
   if (global.rank == 0)
     for (unsigned int t = 0; t < h.cellfields->size(); t++) {
       char it[32]; std::snprintf(it, sizeof(it), "%012u", h.iter);

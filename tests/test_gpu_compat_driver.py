@@ -78,7 +78,10 @@ def test_pipe_driver_validation_bounds(tmp_path, gpu):
     """tests/validation/pipeflow/test_pipeflow.cpp:87-106 on the synthetic pipe: the cell count stays constant,
     relative apparent viscosity in (1.03, 3.0), mean vertex force below 4 pN"""
     exe = _build(tmp_path, "examples/pipe/pipe_synthetic.cpp")
-    r = subprocess.run([exe, "config.xml"], cwd=os.path.join(ROOT, "examples", "pipe"), capture_output=True, text=True, timeout=600)
+    case = str(tmp_path / "pipe"); os.makedirs(case)
+    for f in ("config.xml", "RBC.xml", "PLT.xml", "RBC.pos", "PLT.pos"):
+        shutil.copy(os.path.join(ROOT, "examples", "pipe", f), case)
+    r = subprocess.run([exe, "config.xml"], cwd=case, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     stats = [l.split()[1:] for l in r.stdout.splitlines() if l.startswith("STAT")]
     assert len(stats) == 4
@@ -90,16 +93,20 @@ def test_pipe_driver_validation_bounds(tmp_path, gpu):
         assert force < 4.0, s
     # ---- checkpoint / resume (core/hemoCellFields.cpp:240-319): restart from the dump written at iteration 200 with
     # checkpoint.xml as the configuration, like the reference; the continuation reproduces the remaining lines exactly
-    ck = os.path.join(ROOT, "examples", "pipe", "tmp_pipe", "checkpoint")
+    ck = os.path.join(case, "tmp_pipe", "checkpoint")
     assert os.path.exists(os.path.join(ck, "checkpoint.bin.old")) and os.path.exists(os.path.join(ck, "checkpoint.xml.old"))
     os.replace(os.path.join(ck, "checkpoint.bin.old"), os.path.join(ck, "checkpoint.bin"))     # the iteration-200 dump
     os.replace(os.path.join(ck, "checkpoint.xml.old"), os.path.join(ck, "checkpoint.xml"))
-    r2 = subprocess.run([exe, "tmp_pipe/checkpoint/checkpoint.xml"], cwd=os.path.join(ROOT, "examples", "pipe"), capture_output=True, text=True, timeout=600)
+    r2 = subprocess.run([exe, "tmp_pipe/checkpoint/checkpoint.xml"], cwd=case, capture_output=True, text=True, timeout=600)
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
+    # config/config.cpp:88-174: the constructor opens a fresh directory when the configured one exists (tmp_pipe_0), loading the
+    # checkpoint goes back to the one it names, and the log of the continuation does not overwrite the first (logfile.0)
+    assert os.path.isdir(os.path.join(case, "tmp_pipe_0")) and os.path.exists(os.path.join(case, "tmp_pipe", "log", "logfile.0"))
+    assert "resumed at iteration 200" in open(os.path.join(case, "tmp_pipe", "log", "logfile.0")).read()
     stats2 = [l for l in r2.stdout.splitlines() if l.startswith("STAT")]
     assert stats2 == [l for l in r.stdout.splitlines() if l.startswith("STAT")][2:], (stats2, stats)
     # ---- output layout (io/ParticleHdf5IO.cpp, io/FluidHdf5IO.hh, io/writeCellInfoCSV.cpp:52)
-    out = os.path.join(ROOT, "examples", "pipe", "tmp_pipe")
+    out = os.path.join(case, "tmp_pipe")
     csv = open(os.path.join(out, "csv", "RBC.000000000400.csv")).read().splitlines()
     assert csv[0] == "X,Y,Z,area,volume,atomic_block,cellId,baseCellId,velocity_x,velocity_y,velocity_z" and len(csv) == 26
     if not HAVE_HDF5:
@@ -268,6 +275,101 @@ def _run_case(tmp_path, exe, case):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     log = open(str(work / "tmp" / "log" / "logfile")).read().splitlines()
     return work, log
+
+
+def _run_short(tmp_path, name, tmax, tmeas):
+    """a reference driver on its own inputs (tests/golden/<name>_case = the data files of its directory) with tmax / tmeas cut down"""
+    import re
+    work = tmp_path / name
+    shutil.copytree(os.path.join(ROOT, "tests", "golden", name + "_case"), str(work))
+    for f in os.listdir(str(work)):
+        os.chmod(str(work / f), 0o644)
+    cfg = open(str(work / "config.xml")).read()
+    cfg = re.sub(r"<tmax>[^<]*</tmax>", "<tmax> %d </tmax>" % tmax, cfg); cfg = re.sub(r"<tmeas>[^<]*</tmeas>", "<tmeas> %d </tmeas>" % tmeas, cfg)
+    open(str(work / "config.xml"), "w").write(cfg)
+    r = subprocess.run([_ref_driver(name), "config.xml"], cwd=str(work), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return work, r.stdout.splitlines()
+
+
+def _csv(path):
+    rows = open(path).read().splitlines()
+    return rows[0].split(","), np.array([[float(v) for v in l.split(",")] for l in rows[1:]]).reshape(-1, 11)
+
+
+def test_reference_simple_driver(tmp_path, gpu):
+    """examples/simple/simple.cpp: initializeLattice, a square duct of BounceBack planes, a cell type without cells, every
+    derived fluid field in the output list (:71-74)"""
+    work, out = _run_short(tmp_path, "simple", 1000, 500)
+    assert sum("writing output at timestep" in l for l in out) == 2
+    if not HAVE_HDF5:
+        return
+    f = str(work / "tmp" / "hdf5" / "000000001000" / "Fluid.000000001000.p.0.h5")
+    hdr = subprocess.run(["/opt/conda/bin/h5dump", "-H", f], capture_output=True, text=True).stdout
+    for name, c in (("Velocity", 3), ("Density", 1), ("Force", 3), ("ShearRate", 9), ("StrainRate", 6), ("ShearStress", 6), ("Boundary", 1), ("Omega", 1), ("CellDensity_RBC_HO", 1)):
+        seg = hdr[hdr.index('DATASET "%s"' % name):][:300]
+        assert "( 52, 52, 52, %d )" % c in seg, (name, seg)
+    vel = _h5_array(f, "Velocity").reshape(52, 52, 52, 3)
+    bnd = _h5_array(f, "Boundary").reshape(52, 52, 52)
+    assert vel[26, 26, 26, 0] > 0 and vel[26, 26, 26, 0] == pytest.approx(vel[..., 0].max(), rel=1e-3) and np.abs(vel[bnd == 1]).max() == 0   # duct flow along +x, fastest on the axis
+    frc = _h5_array(f, "Force").reshape(52, 52, 52, 3)
+    assert frc[..., 0].min() == frc[..., 0].max() > 0 and np.abs(frc[..., 1:]).max() == 0     # the driving force the driver wrote after the iteration
+    assert (_h5_array(f, "CellDensity_RBC_HO") == 0).all()
+
+
+def test_reference_cell_collision_driver(tmp_path, gpu):
+    """cases/cellCollision/cellCollision.cpp: iniLatticeSquareCouette shear box with one RBC and one platelet"""
+    work, out = _run_short(tmp_path, "cellCollision", 2000, 1000)
+    assert "(readPositionsBloodCells) 1 complete RBC cells placed." in out and "(readPositionsBloodCells) 1 complete PLT cells placed." in out
+    assert out[-1] == "(CellCollision) Simulation finished :)"
+    for t in ("RBC", "PLT"):
+        h0, c0 = _csv(str(work / "tmp" / "csv" / (t + ".000000000000.csv")))
+        h1, c1 = _csv(str(work / "tmp" / "csv" / (t + ".000000002000.csv")))
+        assert len(c0) == len(c1) == 1
+        assert abs(c1[0, 4] / c0[0, 4] - 1) < 0.02                   # volume kept
+        assert abs(c1[0, 0] - c0[0, 0]) > 1e-9                       # carried along x by the shear flow [m]
+
+
+def test_reference_kolmogorov_driver(tmp_path, gpu):
+    """cases/kolmogorovFlow/kolmogorovFlow.cpp: fully periodic box, +F on one half and -F on the other, written with
+    setExternalVector on two sub-domains before every iteration (:136-140)"""
+    work, out = _run_short(tmp_path, "kolmogorovFlow", 2000, 1000)
+    cells = [l for l in out if "# of cells" in l]
+    assert len(cells) == 2 and len(set(cells)) == 1 and "# of RBC: 10" in cells[0]                 # 105 in the file; none lost on the way
+    vel = [l for l in out if "Velocity  -" in l]
+    vmax, vmean = float(vel[-1].split("max.:")[1].split()[0]), float(vel[-1].split("mean:")[1].split()[0])
+    assert vmax > 1.3 * vmean > 0                                                               # a shear flow, not a uniformly accelerated box
+    if HAVE_HDF5:
+        f = str(work / "tmp" / "hdf5" / "000000002000" / "Fluid.000000002000.p.0.h5")
+        ux = _h5_array(f, "Velocity").reshape(62, 62, 62, 3)[1:-1, 1:-1, 1:-1, 0]                   # [z][y][x]
+        top, bottom = ux[:, :30, :].mean(), ux[:, 30:, :].mean()
+        assert top > 0 > bottom and abs(top + bottom) < 0.05 * top                                 # the two halves stream against each other
+        frc = _h5_array(f, "Force").reshape(62, 62, 62, 3)[1:-1, 1:-1, 1:-1, 0]
+        assert (frc[:, :30, :] > 0).all() and (frc[:, 30:, :] < 0).all() and np.allclose(frc[:, :30, :], -frc[:, 30:, :][:, ::-1, :])
+
+
+def test_reference_parachuting_driver(tmp_path, gpu):
+    """examples/parachuting/parachuting.cpp: one RBC in a narrow voxelised tube (tube.stl), driven flow"""
+    work, out = _run_short(tmp_path, "parachuting", 2000, 500)
+    cells = [l for l in out if "# of cells" in l]
+    assert len(cells) == 4 and all("# of cells: 1 | # of RBC: 1" in l for l in cells)
+    visc = [float(l.split("viscosity:")[1]) for l in out if "viscosity" in l]
+    assert all(0.9 < v < 1.5 for v in visc), visc
+    x = [_csv(str(work / "tmp" / "csv" / ("RBC.%012d.csv" % it)))[1][0, 0] for it in (500, 1000, 1500, 2000)]
+    assert x[0] < x[1] < x[2] < x[3]                                                             # carried downstream
+
+
+def test_reference_parallel_planes_driver(tmp_path, gpu):
+    """examples/parallelplanes/parallelplanes.cpp: channel between two BounceBack planes, periodic in x and y, RBC + PLT
+    suspension from its own .pos files (written for a larger box: what falls outside is not placed)"""
+    work, out = _run_short(tmp_path, "parallelplanes", 1000, 500)
+    log = out                                                                                     # hlog goes to the terminal too
+    cells = [l for l in log if "# of cells" in l]
+    assert len(cells) == 2 and len(set(cells)) == 1                                               # nothing lost between the measurements
+    n = int(cells[0].split("# of cells:")[1].split()[0])
+    assert 300 < n < 1189
+    fmax = [float(l.split("max.:")[1].split()[0]) for l in log if "Force  -" in l]
+    assert all(f < 5.0 for f in fmax), fmax                                                       # pN: a relaxed suspension
 
 
 def _cut(line, *spec):

@@ -143,6 +143,12 @@ inline void writeFluidField_HDF5(HemoCell &h, const string &dir) {
   // answers zero velocity and the density it was constructed with, whatever its populations hold
   if (!L->bounce_back.empty())
     for (size_t k = 0; k < nn; k++) if (L->bounce_back[k + (size_t)x0 * ny * nz]) { rho[k] = L->bb_rho; u[3 * k] = u[3 * k + 1] = u[3 * k + 2] = 0; }
+  // a velocity-condition node answers the velocity it imposes (setBoundaryVelocity; zero until one is given)
+  for (size_t k = 0; k < nn; k++) {
+    const uint8_t m = L->mask[k + (size_t)x0 * ny * nz];
+    if (m == 0 || (!L->bounce_back.empty() && L->bounce_back[k + (size_t)x0 * ny * nz])) continue;
+    for (int d = 0; d < 3; d++) u[3 * k + d] = m >= 3 ? (double)L->wall_u[(size_t)(m - 3)][(size_t)d] : 0.0;
+  }
   const string fileName = dir + "/Fluid." + zeroPadNumber(h.iter) + ".p." + std::to_string(global.rank) + ".h5";
   hid_t file = H5Fcreate(fileName.c_str(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
   double dx = Parameters::dx, dt = Parameters::dt; long it = h.iter; int id = global.rank;

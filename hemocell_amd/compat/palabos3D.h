@@ -285,6 +285,23 @@ void defineDynamics(MultiBlockLattice3D<U, D> &lattice, MultiScalarField3D<int> 
   lattice.dirty_layout = true;
   delete dyn;
 }
+// domain-functional form: the nodes of the box the driver's predicate picks (examples/flowaroundsphere/flowaroundsphere.cpp:38-57,
+// cases/stenosis/stenosis.cpp:38-60)
+struct DomainFunctional3D {
+  virtual ~DomainFunctional3D() {}
+  virtual bool operator()(plint iX, plint iY, plint iZ) const = 0;
+  virtual DomainFunctional3D *clone() const = 0;
+};
+template <typename U, template <typename> class D>
+void defineDynamics(MultiBlockLattice3D<U, D> &lattice, Box3D box, DomainFunctional3D *domain, Dynamics<U, D> *dyn) {
+  const bool wall = dyn->isBoundary();
+  for (plint x = std::max<plint>(box.x0, 0); x <= std::min<plint>(box.x1, lattice.nx - 1); x++)
+    for (plint y = std::max<plint>(box.y0, 0); y <= std::min<plint>(box.y1, lattice.ny - 1); y++)
+      for (plint z = std::max<plint>(box.z0, 0); z <= std::min<plint>(box.z1, lattice.nz - 1); z++)
+        if ((*domain)(x, y, z)) { const size_t k = ((size_t)x * lattice.ny + y) * lattice.nz + z; lattice.mask[k] = wall ? 1 : 0; lattice.note_wall(k, wall, dyn); }
+  lattice.dirty_layout = true;
+  delete domain; delete dyn;
+}
 // box form (e.g. cases with explicit wall slabs)
 template <typename U, template <typename> class D>
 void defineDynamics(MultiBlockLattice3D<U, D> &lattice, Box3D box, Dynamics<U, D> *dyn) {

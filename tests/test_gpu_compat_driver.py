@@ -372,6 +372,30 @@ def test_reference_parallel_planes_driver(tmp_path, gpu):
     assert all(f < 5.0 for f in fmax), fmax                                                       # pN: a relaxed suspension
 
 
+def test_reference_flow_around_sphere_driver(tmp_path, gpu):
+    """examples/flowaroundsphere/flowaroundsphere.cpp: a sphere of BounceBack nodes from the driver's own plb::DomainFunctional3D,
+    a moving top wall (velocity condition), periodic in x and y, RBC + PLT suspension with the cell-cell repulsion switched on"""
+    work, out = _run_short(tmp_path, "flowaroundsphere", 400, 200)
+    cells = [l for l in out if "# of cells" in l]
+    assert len(cells) == 2 and len(set(cells)) == 1 and int(cells[0].split("# of cells:")[1].split()[0]) > 500
+    vmax = [float(l.split("max.:")[1].split()[0]) for l in out if "Velocity  -" in l]
+    assert all(0.02 < v <= 0.0338 for v in vmax), vmax        # the wall moves at 0.75 * 1800 1/s * 100 um / 4 = 33.75 mm/s; nothing is faster
+    if HAVE_HDF5:
+        f = str(work / "tmp" / "hdf5" / "000000000400" / "Fluid.000000000400.p.0.h5")
+        ux = _h5_array(f, "Velocity").reshape(102, 102, 202, 3)[..., 0]
+        assert np.abs(ux[1 + 15, 1 + 50, 1 + 50]) == 0 and ux[100, 51, 101] == pytest.approx(0.03375, rel=1e-5)   # inside the sphere; on the moving wall
+
+
+def test_reference_bent_microvessel_driver(tmp_path, gpu):
+    """cases/microvessel_bended/microvessel_bended.cpp: a sinusoidally bent vessel from a DomainFunctional3D, fully periodic
+    box, 20 000 warm-up steps of the fluid alone, then the suspension"""
+    work, out = _run_short(tmp_path, "microvessel_bended", 400, 200)
+    cells = [l for l in out if "# of cells" in l]
+    assert len(cells) == 2 and len(set(cells)) == 1 and int(cells[0].split("# of cells:")[1].split()[0]) > 200
+    visc = [float(l.split("viscosity:")[1]) for l in out if "viscosity:" in l]
+    assert len(visc) == 2 and all(0.9 < v < 1.3 for v in visc), visc
+
+
 def _cut(line, *spec):
     """cut -d<delim> -f<n> chains of the CI scripts"""
     for delim, n in spec:

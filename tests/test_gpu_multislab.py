@@ -27,7 +27,7 @@ FORCE = (3e-4, 0.0, 0.0)
 REPULSION = dict(k=2e-6, cutoff_um=0.7, k_b=3e-6, b_cutoff_um=1.0)   # examples/pipeflow/config.xml:36-38 magnitudes
 
 
-def _build(rank, world, rep=False, padded=False, cells=CELLS, plts=PLTS, force=FORCE, nxg=NXG, del_mode=None, k_p=K_P, push=None):
+def _build(rank, world, rep=False, padded=False, cells=CELLS, plts=PLTS, force=FORCE, nxg=NXG, del_mode=None, k_p=K_P, push=None, regions=None):
     from hemocell_amd import host
     from hemocell_amd.slab import SlabRunner
     host.check(host.capi.lib().hc_debug_force_plane_padding(1 if padded else 0))   # padded x-plane stride (hc_lattice::xs)
@@ -38,6 +38,8 @@ def _build(rank, world, rep=False, padded=False, cells=CELLS, plts=PLTS, force=F
     r.define_bounce_back(mask)
     r.lattice.latticeEquilibrium(1.0, (0, 0, 0))
     r.lattice.setExternalVector(force)
+    if regions:   # setExternalVector on sub-domains, in GLOBAL node coordinates on every rank
+        r.lattice.setExternalVectorBoxes([b for b, _ in regions], [f for _, f in regions])
     r.add_cell_type(host.CellType.rbc(P))
     r.add_cell_type(host.CellType.plt(P))
     if del_mode:
@@ -160,6 +162,31 @@ def test_slabs_match_single_domain(tmp_path, gpu, world, rep, padded):
             assert np.allclose(got[:3], want[:3], rtol=1e-6, atol=1e-18), (got, want)
     travelled = np.abs(allpos[:, 0] - _initial_x()).max()
     assert travelled > 5.0, travelled
+
+
+# sub-domain forces (cases/kolmogorovFlow/kolmogorovFlow.cpp:136-140): one box across the slab face at x = 72, one across the seam
+# (two boxes, since a box does not wrap), one inside a slab that overrides part of the first
+REGIONS = [((40, 100, 0, NY - 1, 0, NZ - 1), (1e-4, 0.0, 2e-5)), ((130, NXG - 1, 0, NY - 1, 0, NZ // 2), (-2e-4, 1e-5, 0.0)),
+           ((0, 12, 0, NY - 1, 0, NZ // 2), (-2e-4, 1e-5, 0.0)), ((60, 80, 10, 20, 0, NZ - 1), (0.0, 0.0, -3e-5))]
+
+
+def test_slabs_with_subdomain_forces_match_single_domain(tmp_path, gpu):
+    res = _spawn(2, tmp_path, dict(regions=REGIONS), steps=120, salt=7)
+    ref, mask = _build(0, 1, regions=REGIONS)
+    ref.run(120)
+    f_ref = ref.lattice.populations().reshape(NXG, NY * NZ, 19)
+    f_two = np.concatenate([r["f"].reshape(NXG // 2, NY * NZ, 19) for r in res], axis=0)
+    fluid = (mask.reshape(NXG, NY * NZ) == 0)
+    assert np.abs(f_two - f_ref)[fluid].max() <= 5e-12
+    plain, _ = _build(0, 1)
+    plain.run(120)
+    assert np.abs(plain.lattice.populations().reshape(NXG, NY * NZ, 19) - f_ref)[fluid].max() > 1e-6     # the boxes do act
+    allpos = ref.cells.positions
+    nrbc = len(CELLS) * 642
+    for r in res:
+        d = r["pos"] - allpos[:nrbc].reshape(len(CELLS), -1, 3)[r["cid"], r["vid"]]
+        d[:, 0] = (d[:, 0] + NXG / 2) % NXG - NXG / 2
+        assert np.abs(d).max() <= 1e-10
 
 
 # a cell that is pushed into the pipe wall next to the slab face at x = 72 (both ranks hold a copy): every holder must drop it

@@ -3,7 +3,10 @@
 //                                         HemoCellField::kernelMethod, CellMechanics::cellConstants, phase methods of HemoCellFields
 //   plugin_driver usermodel <config.xml>  addCellType<user model> -> refused with log + exit(1)
 //   plugin_driver userkernel <config.xml> a user IBM kernelMethod -> refused with log + exit(1)
+//   plugin_driver forceonce <config.xml>  setExternalVector ONCE, then ten iterations: the reference zeroes the field at the end of
+//                                         every iterate() (core/hemoCell.cpp:369-371), so only the first one is driven
 #include "hemocell.h"
+#include "fluidInfo.h"
 #include "rbcHighOrderModel.h"
 #include "user_model.h"
 #include <cstring>
@@ -41,6 +44,19 @@ int main(int argc, char *argv[]) {
   if (mode == "userkernel") field.kernelMethod = myKernel;
   hemocell.loadParticles();
   if (mode == "userkernel") { std::cout << "NOT REFUSED" << std::endl; return 0; }
+  if (mode == "forceonce") {
+    const T F = 1e-5;
+    setExternalVector(*hemocell.lattice, hemocell.lattice->getBoundingBox(), DESCRIPTOR<T>::ExternalField::forceBeginsAt, plb::Array<T, 3>(F, 0., 0.));
+    for (int it = 0; it < 10; it++) hemocell.iterate();
+    FluidStatistics once = FluidInfo::calculateVelocityStatistics(&hemocell);
+    for (int it = 0; it < 10; it++) {   // the pattern of the shipped drivers: written again after every iteration
+      hemocell.iterate();
+      setExternalVector(*hemocell.lattice, hemocell.lattice->getBoundingBox(), DESCRIPTOR<T>::ExternalField::forceBeginsAt, plb::Array<T, 3>(F, 0., 0.));
+    }
+    FluidStatistics again = FluidInfo::calculateVelocityStatistics(&hemocell);
+    std::printf("forceonce F %.6e after_ten_with_one_write %.6e after_ten_more_written_every_time %.6e\n", F, once.avg, again.avg);
+    return 0;
+  }
 
   // mechanics/cellMechanics.h:39: the constants a model reads
   const CommonCellConstants &cc = field.mechanics->cellConstants;

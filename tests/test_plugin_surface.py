@@ -54,3 +54,18 @@ def test_host_plugins_are_refused_like_the_reference_refuses(tmp_path, gpu, mode
     r = subprocess.run([exe, mode, "config.xml"], cwd=d, capture_output=True, text=True, timeout=300)
     assert r.returncode == 1 and fragment in r.stdout and "NOT REFUSED" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert fragment in open(os.path.join(d, "tmp", "log", "logfile")).read()
+
+
+@pytest.mark.gpu
+def test_external_field_is_zeroed_by_iterate_as_in_the_reference(tmp_path, gpu):
+    """core/hemoCell.cpp:369-371: every iterate() ends with setExternalVector(..., 0); a driver that writes its force once drives
+    one iteration only, one that writes it after every iteration (all shipped drivers) drives all of them"""
+    exe = _build(str(tmp_path)); d = _case(tmp_path)
+    r = subprocess.run([exe, "forceonce", "config.xml"], cwd=d, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l.split() for l in r.stdout.splitlines() if l.startswith("forceonce")][0]
+    F, once, again = float(line[2]), float(line[4]), float(line[6])
+    assert 0.8 * F < once < 1.2 * F               # one iteration's worth of momentum in a fully periodic box (rho = 1)
+    # second loop: its first iteration finds the field zeroed, the other nine are driven, and the last write is seen by the
+    # statistics as F / 2 in Cell::computeVelocity but not yet by a step: 9.5 F more
+    assert 9.0 * F < again - once < 10.0 * F

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/r2prof.sh <tag>   (run on the GPU box from the repo root)
+# usage: profiles/scripts/r2prof.sh <tag>   (run on the GPU box from the repo root)
 set -o pipefail
 T=$1; OUT=gpurun_out/$T; mkdir -p $OUT
 export TMPDIR=/tmp

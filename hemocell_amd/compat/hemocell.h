@@ -874,6 +874,7 @@ inline void HemoCell::loadCheckPoint() {
 // ------------------------------------------------------------------ helper/cellInfo.h
 struct CellInformation {
   hemo::Array<T, 3> position; T volume = 0, area = 0, stretch = 0; hemo::Array<T, 6> bbox; pluint cellType = 0; plint base_cell_id = 0; bool centerLocal = true; plint blockId = 0;
+  hemo::Array<T, 3> velocity;   // mean of the vertices' sv.v (helper/cellInfo.cpp:216-217, :252)
 };
 struct CellInformationFunctionals {
   static map<int, CellInformation> &info() { static map<int, CellInformation> m; return m; }
@@ -886,11 +887,12 @@ struct CellInformationFunctionals {
     const double g = std::floor(cx + 0.5);
     return g >= (double)L->x0 && g < (double)(L->x0 + L->nxl);
   }
-  static void fill(HemoCell *h, bool vol, bool area, bool pos, bool bbox, bool stretch) {
+  static void fill(HemoCell *h, bool vol, bool area, bool pos, bool bbox, bool stretch, bool vel = false) {
     hc_cells *c = h->cellfields->device();
     long nvt = 0, nct = 0; hcp_counts(c, &nvt, &nct, nullptr);
     vector<long> ids((size_t)nct); if (nct) hcp_download_cell_ids(c, ids.data());
     vector<double> allpos; if (stretch) { allpos.resize(3 * (size_t)nvt); if (nvt) hcp_download(c, 0, allpos.data()); }
+    vector<double> allvel; if (vel) { allvel.resize(3 * (size_t)nvt); if (nvt) hcp_download(c, 1, allvel.data()); }
     long first_cell = 0;
     for (unsigned int t = 0; t < h->cellfields->size(); t++) {
       long fv = 0, nc = 0; hcp_type_range(c, (int)t, &fv, &nc);
@@ -906,6 +908,10 @@ struct CellInformationFunctionals {
         if (area) ci.area = A[(size_t)k];
         if (pos) for (int d = 0; d < 3; d++) ci.position[d] = P[3 * (size_t)k + d];
         if (bbox) for (int d = 0; d < 6; d++) ci.bbox[d] = B[6 * (size_t)k + d];
+        if (vel) {
+          const double *vv = allvel.data() + 3 * (size_t)(fv + k * nv);
+          for (int d = 0; d < 3; d++) { T sum = 0; for (int i = 0; i < nv; i++) sum += vv[3 * i + d]; ci.velocity[d] = sum / T(nv); }
+        }
         if (stretch) {   // helper/cellInfo.cpp:124-138: largest vertex-vertex distance
           T mx = 0; const double *pp = allpos.data() + 3 * (size_t)(fv + k * nv);
           for (int i = 0; i < nv - 1; i++) for (int jv = i + 1; jv < nv; jv++) {
@@ -923,7 +929,12 @@ struct CellInformationFunctionals {
   static void calculateCellPosition(HemoCell *h) { fill(h, false, false, true, false, false); }
   static void calculateCellBoundingBox(HemoCell *h) { fill(h, false, false, false, true, false); }
   static void calculateCellStretch(HemoCell *h) { fill(h, false, false, false, false, true); }
-  static void calculateCellInformation(HemoCell *h) { fill(h, true, true, true, true, false); }
+  static void calculateCellVelocity(HemoCell *h) { fill(h, false, false, false, false, false, true); }
+  static void calculateCellAtomicBlock(HemoCell *h) { fill(h, false, false, false, false, false); }   // blockId and cellType come with every entry
+  static void calculateCellType(HemoCell *h) { fill(h, false, false, false, false, false); }
+  static void calculate_vol_pos_area(HemoCell *h) { fill(h, true, true, true, false, false); }        // helper/cellInfo.h:107: "excludes Stretch"
+  static void calculateCellInformation(HemoCell *h) { fill(h, true, true, true, true, false, true); }
+  static void calculateCellInformation(HemoCell *h, map<int, CellInformation> &out) { clear_list(); calculateCellInformation(h); out = info(); clear_list(); }   // :121
   static void clear_list() { info().clear(); }
   // helper/cellInfo.cpp:324-365: centre-local cells of every rank, summed (HemoCellGatheringFunctional)
   static vector<double> counts_per_type(HemoCell *h) {
@@ -984,13 +995,15 @@ inline void writeCellInfo_CSV(HemoCell &h) {
   CellInformationFunctionals::clear_list();
   CellInformationFunctionals::calculateCellInformation(&h);
   // every rank holds its centre-local cells; rank 0 gathers and writes (HemoCellGatheringFunctional, :45)
-  struct Row { double v[8]; };   // x y z area volume block cellId type
+  struct Row { double v[11]; };   // x y z area volume block cellId type velocity
   vector<Row> mine;
   for (auto &kv : CellInformationFunctionals::info()) {
     const CellInformation &c = kv.second; Row r;
     const double sx = h.outputInSiUnits ? Parameters::dx : 1.0;
     r.v[0] = c.position[0] * sx; r.v[1] = c.position[1] * sx; r.v[2] = c.position[2] * sx; r.v[3] = c.area * sx * sx; r.v[4] = c.volume * sx * sx * sx;
     r.v[5] = (double)c.blockId; r.v[6] = (double)kv.first; r.v[7] = (double)c.cellType;
+    const double sv = h.outputInSiUnits ? Parameters::dx / Parameters::dt : 1.0;
+    for (int d = 0; d < 3; d++) r.v[8 + d] = c.velocity[d] * sv;
     mine.push_back(r);
   }
   vector<Row> all = mine;
@@ -1013,7 +1026,8 @@ inline void writeCellInfo_CSV(HemoCell &h) {
       f << "X,Y,Z,area,volume,atomic_block,cellId,baseCellId,velocity_x,velocity_y,velocity_z" << std::endl;   // :52
       for (const Row &r : all) {
         if ((unsigned int)r.v[7] != t) continue;
-        f << r.v[0] << "," << r.v[1] << "," << r.v[2] << "," << r.v[3] << "," << r.v[4] << "," << (long)r.v[5] << "," << (long)r.v[6] << "," << (long)r.v[6] << ",0,0,0" << std::endl;
+        f << r.v[0] << "," << r.v[1] << "," << r.v[2] << "," << r.v[3] << "," << r.v[4] << "," << (long)r.v[5] << "," << (long)r.v[6] << "," << (long)r.v[6] << ","
+          << r.v[8] << "," << r.v[9] << "," << r.v[10] << std::endl;
       }
     }
   CellInformationFunctionals::clear_list();

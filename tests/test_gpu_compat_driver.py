@@ -139,6 +139,8 @@ def test_pipe_driver_validation_bounds(tmp_path, gpu):
     vid = _h5_array(rbc, "Vertex Id").reshape(25, 642)
     assert (vid == np.arange(642)[None, :]).all()
     rows = {int(l.split(",")[6]): [float(x) for x in l.split(",")[:5]] for l in csv[1:]}
+    cellv = np.array([[float(x) for x in l.split(",")[8:11]] for l in csv[1:]])            # mean vertex velocity of every cell [m/s] (helper/cellInfo.cpp:216-217)
+    assert (cellv[:, 0] > 0).all() and cellv[:, 0].max() < 0.05 and np.abs(cellv[:, 1:]).max() < 0.2 * cellv[:, 0].max()   # carried along +x
     assert sorted(rows) == sorted(cid.tolist())
     Lx = 100 * 0.5e-6                                                                     # the pipe is periodic along x: the writer wraps vertex by vertex
     for k, c in enumerate(cid):

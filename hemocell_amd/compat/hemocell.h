@@ -559,7 +559,22 @@ class HemoCell {
     (*cellfields)[name]->minimumDistanceFromSolid = distance;
   }
   void setSystemPeriodicity(unsigned int axis, bool bePeriodic) { lattice->periodicity().toggle((int)axis, bePeriodic); }
-  void setSystemPeriodicityLimit(unsigned int, int) {}
+  void setSystemPeriodicityLimit(unsigned int, int) {}   // how often a cell id may wrap (core/hemoCell.cpp): ids are not shifted here
+  // ---- the rest of hemocell.h:86-253.  Features outside the path are refused the way the reference refuses
+  // what it cannot do -- a line in the log and exit(1) -- never ignored
+  void refuse(const char *what) { hlog << "(HemoCell) (GPU backend) " << what << " is not part of this back end (DESIGN.md section 0), exiting ..." << endl; std::exit(1); }
+  void enableSolidifyMechanics(string) { refuse("solidify mechanics (enableSolidifyMechanics)"); }
+  void setSolidifyTimeScaleSeperation(unsigned int) { refuse("solidify mechanics (setSolidifyTimeScaleSeperation)"); }
+  void setInteriorViscosityTimeScaleSeperation(unsigned int, unsigned int) { refuse("interior viscosity (setInteriorViscosityTimeScaleSeperation)"); }
+  void setCEPACOutputs(vector<int>) { refuse("the CEPAC field (setCEPACOutputs)"); }
+  void checkExitSignals() {}                                   // core/hemoCell.cpp:300: SIGINT / SIGTERM handling of the reference's run scripts
+  void sanityCheck() { sanityCheckDone = true; }               // the facade's own checks run where a setting is used
+  // one x-slab per rank and GPU is the only layout: nothing to measure against, nothing to move
+  T calculateFractionalLoadImbalance() { hlog << "(HemoCell) (LoadBalancer) one x-slab per rank: fractional load imbalance is reported as 0" << endl; return 0; }
+  void doLoadBalance() { hlog << "(HemoCell) (LoadBalancer) one x-slab per rank: nothing to balance" << endl; }
+  void doRestructure(bool = true) { hlog << "(HemoCell) (LoadBalancer) one x-slab per rank: nothing to restructure" << endl; }
+  bool loadParticlesIsCalled = false, sanityCheckDone = false, partOfpreInlet = false, leesEdwardsBC = false;
+  unsigned int lastOutputAt = 0;
   void loadParticles();
   void loadCheckPoint();
   void saveCheckPoint();
@@ -746,6 +761,7 @@ inline void HemoCellFields::deleteIncompleteCells(bool verbose) { particleField.
 
 // io/readPositionsBloodCells.cpp:205-361: "<name>.pos": N, then x y z (um) rx ry rz (deg) per cell
 inline void HemoCell::loadParticles() {
+  loadParticlesIsCalled = true;
   hc_cells *c = cellfields->device();
   int total = 0, cellid = 0;
   for (unsigned int j = 0; j < cellfields->size(); j++) { std::ifstream f(((*cellfields)[j]->name + ".pos").c_str()); int n = 0; if (f.is_open()) f >> n; total += n; }
@@ -1039,6 +1055,7 @@ namespace hemo {
 
 // core/hemoCell.cpp:221-287: <out>/hdf5/<iter>/ with one file per cell type plus the fluid file, and the CSV summary
 inline void HemoCell::writeOutput() {
+  lastOutputAt = iter;
   cellfields->deleteIncompleteCells(global.cellsDeletedInfo);   // core/hemoCell.cpp:248-252: the writers expect whole cells
 #ifdef HEMOCELL_WITH_HDF5
   const string dir = outDir + "/hdf5/" + zeroPadNumber(iter);

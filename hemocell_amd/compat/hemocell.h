@@ -438,6 +438,20 @@ class HemoCellFields {
   inline void applyConstitutiveModel(bool forced = false);
   inline void deleteIncompleteCells(bool verbose = true);
   inline void syncEnvelopes() {}   // part of the slab schedule inside hc_iterate (csrc/slab.hip)
+  inline void deleteNonLocalParticles(int) {}   // likewise: a copy nobody refreshes any more is dropped at the next envelope synchronisation
+  inline void applyRepulsionForce();            // core/hemoCellFields.cpp:527-540 (cadence is the caller's business, as in the reference)
+  inline void applyBoundaryRepulsionForce();
+  inline void populateBoundaryParticles() {}    // the flag map of the wall nodes is built by enableBoundaryParticles
+  inline void separate_force_vectors() {}       // the separate vectors are evaluated when they are written (compat/hdf5_output.h)
+  inline void unify_force_vectors() {}
+  inline void updateResidenceTime(unsigned int) {}   // "Res Time" is written as zeros
+  void refuse(const char *what);   // log + exit(1), like HemoCell::refuse
+  inline void solidifyCells() { refuse("solidify mechanics (solidifyCells)"); }
+  inline void prepareSolidification() { refuse("solidify mechanics (prepareSolidification)"); }
+  inline void populateBindingSites(plb::Box3D * = nullptr) { refuse("binding sites (populateBindingSites)"); }
+  inline void findInternalParticleGridPoints() { refuse("interior viscosity (findInternalParticleGridPoints)"); }
+  inline void internalGridPointsMembrane() { refuse("interior viscosity (internalGridPointsMembrane)"); }
+  inline void createCEPACfield() { refuse("the CEPAC field (createCEPACfield)"); }
 };
 
 // ------------------------------------------------------------------ hemocell.h:68-253
@@ -758,6 +772,17 @@ inline void HemoCellFields::interpolateFluidVelocity() { hc_check(hcp_interpolat
 inline void HemoCellFields::advanceParticles() { hc_check(hcp_advance(device(), 0), "hcp_advance"); particleField.invalidate(); }
 inline void HemoCellFields::applyConstitutiveModel(bool forced) { hc_check(hcp_mechanics(device(), (long)hemocell.iter, forced ? 1 : 0), "hcp_mechanics"); particleField.invalidate(); }
 inline void HemoCellFields::deleteIncompleteCells(bool verbose) { particleField.deleteIncompleteCells(verbose); }
+inline void HemoCellFields::applyRepulsionForce() {
+  HemoCell &h = hemocell; hc_cells *c = device();
+  if (h.repulsionEnabled && !h.repulsionPushed) { hc_check(hcp_set_repulsion(c, h.repulsionConstant_, h.repulsionCutoff_, (int)h.repulsionTimescale), "hcp_set_repulsion"); h.repulsionPushed = true; }
+  hc_check(hcp_repulsion(c), "hcp_repulsion"); particleField.invalidate();
+}
+inline void HemoCellFields::applyBoundaryRepulsionForce() {
+  HemoCell &h = hemocell; hc_cells *c = device();
+  if (h.boundaryRepulsionEnabled && !h.boundaryRepulsionPushed) { hc_check(hcp_set_boundary_repulsion(c, h.boundaryRepulsionConstant_, h.boundaryRepulsionCutoff_, (int)h.boundaryRepulsionTimescale), "hcp_set_boundary_repulsion"); h.boundaryRepulsionPushed = true; }
+  hc_check(hcp_boundary_repulsion(c), "hcp_boundary_repulsion"); particleField.invalidate();
+}
+inline void HemoCellFields::refuse(const char *what) { hemocell.refuse(what); }
 
 // io/readPositionsBloodCells.cpp:205-361: "<name>.pos": N, then x y z (um) rx ry rz (deg) per cell
 inline void HemoCell::loadParticles() {

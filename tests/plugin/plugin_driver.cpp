@@ -82,6 +82,14 @@ int main(int argc, char *argv[]) {
   hemocell.iterate();
   CellInformationFunctionals::calculateCellPosition(&hemocell);
   for (auto &kv : CellInformationFunctionals::info_per_cell) std::cout << "cell " << kv.first << " y " << kv.second.position[1] << std::endl;
+  // phase methods a driver may call one by one (core/hemoCellFields.h:103-158)
+  hemocell.setRepulsion(2e-22, 0.7);
+  hemocell.cellfields->applyRepulsionForce();
+  hemocell.cellfields->separate_force_vectors(); hemocell.cellfields->unify_force_vectors();
+  hemocell.cellfields->syncEnvelopes(); hemocell.cellfields->deleteNonLocalParticles(3);
+  hemocell.doLoadBalance();
+  if (hemocell.calculateFractionalLoadImbalance() != 0) { std::cout << "load imbalance of a single slab is not 0" << std::endl; return 1; }
+  hemocell.iterate();
   std::cout << "SURFACE OK" << std::endl;
   return 0;
 }

@@ -225,6 +225,10 @@ class HemoCell;
 class HemoCellFields;
 class HemoCellField;
 class HemoCellParticleField;
+}  // namespace hemo
+namespace plb { template <class PF> struct MultiParticleField3D; }
+namespace hemo {
+class HemoCellParticleField;
 template <typename U> struct CEPAC_DESCRIPTOR_T { enum { d = 3, q = 19 }; };
 #define CEPAC_DESCRIPTOR hemo::CEPAC_DESCRIPTOR_T   // config/constant_defaults.h:62-65 (only named in signatures here)
 
@@ -332,6 +336,18 @@ class HemoCellField {
   }
   void statistics();
   void create_device_type(int model);
+  // the rest of core/hemoCellField.h:41-83
+  T restingCellVolume = 0; bool outputTriangles = false, doSolidifyMechanics = false, doInteriorViscosity = false; T interiorViscosityTau = 1.0;
+  string getIdentifier() const { return name; }
+  int getNumberOfCells_Global() const { return 0; }   // core/hemoCellField.cpp:192 answers 0 as well
+  void setOutputVariables(const vector<int> &outputs) {   // :139-147 (OUTPUT_TRIANGLES stays in the list here; the writer looks for it)
+    desiredOutputVariables = outputs;
+    outputTriangles = std::find(outputs.begin(), outputs.end(), OUTPUT_TRIANGLES) != outputs.end();
+  }
+  inline plb::MultiParticleField3D<HemoCellParticleField> *getParticleField3D();
+  inline plb::MultiParticleField3D<HemoCellParticleField> *getParticleArg();
+  inline plb::MultiBlockLattice3D<T, DESCRIPTOR> *getFluidField3D();
+  void addSingleCell(hemo::Array<T, 3>, plint) { std::cerr << "(HemoCell) (ParticleType) addSingleCell not implemented, but might definitely be nice to have" << std::endl; std::exit(1); }   // :171-174, word for word
 };
 
 // selects the device model before the CellMechanics base builds the tables
@@ -642,7 +658,12 @@ class HemoCell {
   vector<int> fluidOutputs;
 };
 
-inline void HemoCellField::statistics() { if (mechanics) mechanics->statistics(); }
+inline void HemoCellField::statistics() {   // core/hemoCellField.cpp:176-182
+  hlog << "Cellfield  (+ material model) of " << name << std::endl;
+  hlog << "  Volume :" << volume << " µm³ VolumeFraction of lsp per fluid node: " << volumeFractionOfLspPerNode << " %" << endl;
+  hlog << "  Nvertex: " << numVertex << endl;
+  if (mechanics) mechanics->statistics();
+}
 
 // core/hemoCellField.cpp:38-118: material XML -> mesh + tables on the device
 inline void HemoCellField::create_device_type(int model) {
@@ -783,6 +804,9 @@ inline void HemoCellFields::applyBoundaryRepulsionForce() {
   hc_check(hcp_boundary_repulsion(c), "hcp_boundary_repulsion"); particleField.invalidate();
 }
 inline void HemoCellFields::refuse(const char *what) { hemocell.refuse(what); }
+inline plb::MultiParticleField3D<HemoCellParticleField> *HemoCellField::getParticleField3D() { return cellFields->immersedParticles; }
+inline plb::MultiParticleField3D<HemoCellParticleField> *HemoCellField::getParticleArg() { return cellFields->immersedParticles; }
+inline plb::MultiBlockLattice3D<T, DESCRIPTOR> *HemoCellField::getFluidField3D() { return cellFields->hemocell.lattice; }
 
 // io/readPositionsBloodCells.cpp:205-361: "<name>.pos": N, then x y z (um) rx ry rz (deg) per cell
 inline void HemoCell::loadParticles() {

@@ -77,7 +77,7 @@ def _mesh_worker(rank, world, port, periodic, q):
         q.put((rank, "FAILED: %r" % (e,)))
 
 
-@pytest.mark.parametrize("world,periodic", [(2, True), (3, True), (2, False), (3, False)])
+@pytest.mark.parametrize("world,periodic", [(2, True), (3, True), (2, False), (3, False), (8, True)])   # 8: the node the scaling runs use
 def test_mesh_routing_and_reductions(world, periodic):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

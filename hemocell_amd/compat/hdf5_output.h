@@ -136,18 +136,53 @@ inline void writeFluidField_HDF5(HemoCell &h, const string &dir) {
   if (h.fluidOutputs.empty()) return;
   auto *L = h.lattice; hc_lattice *d = L->device();
   const plint nx = L->nxl, ny = L->ny, nz = L->nz, x0 = L->x0;   // this rank's block
-  const size_t nn = (size_t)nx * ny * nz;
-  vector<double> rho(nn), u(3 * nn);
-  hc_check(hcl_download_rho_u(d, rho.data(), u.data()), "hcl_download_rho_u");
-  // cell.computeVelocity / computeDensity go through the node's dynamics (io/FluidHdf5IO.hh:223,273): a BounceBack node
-  // answers zero velocity and the density it was constructed with, whatever its populations hold
-  if (!L->bounce_back.empty())
-    for (size_t k = 0; k < nn; k++) if (L->bounce_back[k + (size_t)x0 * ny * nz]) { rho[k] = L->bb_rho; u[3 * k] = u[3 * k + 1] = u[3 * k + 2] = 0; }
-  // a velocity-condition node answers the velocity it imposes (setBoundaryVelocity; zero until one is given)
-  for (size_t k = 0; k < nn; k++) {
-    const uint8_t m = L->mask[k + (size_t)x0 * ny * nz];
-    if (m == 0 || (!L->bounce_back.empty() && L->bounce_back[k + (size_t)x0 * ny * nz])) continue;
-    for (int d = 0; d < 3; d++) u[3 * k + d] = m >= 3 ? (double)L->wall_u[(size_t)(m - 3)][(size_t)d] : 0.0;
+  const size_t plane = (size_t)ny * nz, nn = (size_t)nx * plane, ne = (size_t)(nx + 2) * plane;
+  // Every field lives on the block plus one x-plane on either side (index (x + 1) * plane + y * nz + z, x = -1 .. nx): the
+  // reference writes a one-node envelope around each block, filled from the neighbouring block (io/FluidHdf5IO.hh:215-287 loop
+  // over odomain +- 1).  The planes come from the periodic image on one rank, from the neighbour rank's face otherwise, and
+  // repeat the face where the domain ends.  y and z envelopes wrap or repeat locally.
+  auto gx = [&](plint x) -> plint {   // global plane of local plane x, -1 where the domain ends
+    plint g = x0 + x;
+    if (g < 0 || g >= L->nx) { if (!L->per.p[0]) return -1; g = ((g % L->nx) + L->nx) % L->nx; }
+    return g;
+  };
+  auto fill_ends = [&](vector<double> &a, int C) {   // a: [(nx + 2) * plane][C], interior already in place
+    const size_t pc = plane * (size_t)C;
+    if (global.world > 1) {
+      vector<double> rlo(pc), rhi(pc);
+      hc_check(hc_comm_exchange_host(L->per.p[0] ? 1 : 0, a.data() + pc, pc * sizeof(double), a.data() + (size_t)nx * pc, pc * sizeof(double), rlo.data(), pc * sizeof(double),
+                                     rhi.data(), pc * sizeof(double)), "hc_comm_exchange_host");
+      if (gx(-1) >= 0) std::copy(rlo.begin(), rlo.end(), a.begin());
+      if (gx(nx) >= 0) std::copy(rhi.begin(), rhi.end(), a.begin() + (size_t)(nx + 1) * pc);
+    } else if (L->per.p[0]) {
+      std::copy(a.begin() + (size_t)nx * pc, a.begin() + (size_t)(nx + 1) * pc, a.begin());
+      std::copy(a.begin() + pc, a.begin() + 2 * pc, a.begin() + (size_t)(nx + 1) * pc);
+    }
+    if (gx(-1) < 0) std::copy(a.begin() + pc, a.begin() + 2 * pc, a.begin());
+    if (gx(nx) < 0) std::copy(a.begin() + (size_t)nx * pc, a.begin() + (size_t)(nx + 1) * pc, a.begin() + (size_t)(nx + 1) * pc);
+  };
+  // node classes of the extended block from the global flags
+  vector<uint8_t> maskx(ne), bbx(ne, 0);
+  for (plint x = -1; x <= nx; x++) {
+    const plint g = gx(x) >= 0 ? gx(x) : gx(x < 0 ? 0 : nx - 1);
+    std::copy(L->mask.begin() + (size_t)g * plane, L->mask.begin() + (size_t)(g + 1) * plane, maskx.begin() + (size_t)(x + 1) * plane);
+    if (!L->bounce_back.empty()) std::copy(L->bounce_back.begin() + (size_t)g * plane, L->bounce_back.begin() + (size_t)(g + 1) * plane, bbx.begin() + (size_t)(x + 1) * plane);
+  }
+  vector<double> rho(ne), u(3 * ne);
+  {
+    vector<double> r0(nn), u0(3 * nn);
+    hc_check(hcl_download_rho_u(d, r0.data(), u0.data()), "hcl_download_rho_u");
+    std::copy(r0.begin(), r0.end(), rho.begin() + plane); std::copy(u0.begin(), u0.end(), u.begin() + 3 * plane);
+  }
+  fill_ends(rho, 1); fill_ends(u, 3);
+  // cell.computeVelocity / computeDensity go through the node's dynamics (io/FluidHdf5IO.hh:223,273): a BounceBack node answers
+  // zero velocity and the density it was constructed with, whatever its populations hold; a velocity-condition node the
+  // velocity it imposes (setBoundaryVelocity; zero until one is given)
+  for (size_t k = 0; k < ne; k++) {
+    const uint8_t m = maskx[k];
+    if (m == 0) continue;
+    if (bbx[k]) { rho[k] = L->bb_rho; u[3 * k] = u[3 * k + 1] = u[3 * k + 2] = 0; continue; }
+    for (int c = 0; c < 3; c++) u[3 * k + c] = m >= 3 ? (double)L->wall_u[(size_t)(m - 3)][(size_t)c] : 0.0;
   }
   const string fileName = dir + "/Fluid." + zeroPadNumber(h.iter) + ".p." + std::to_string(global.rank) + ".h5";
   hid_t file = H5Fcreate(fileName.c_str(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
@@ -162,6 +197,11 @@ inline void writeFluidField_HDF5(HemoCell &h, const string &dir) {
   H5LTset_attribute_int(file, "/", "numberOfCells", &ncells, 1); H5LTset_attribute_int(file, "/", "subdomainSize", sub, 3);
   H5LTset_attribute_float(file, "/", "relativePosition", rel, 3); H5LTset_attribute_float(file, "/", "dxdydz", dxdydz, 3);
   auto src = [&](plint v, plint n, bool per) { if (v < 0 || v >= n) return per ? ((v % n) + n) % n : std::min<plint>(std::max<plint>(v, 0), n - 1); return v; };
+  // extended index of output node (x, y, z), x in -1 .. nx (beyond that: the outermost plane again), y and z in -1 .. n
+  auto node_of = [&](plint x, plint y, plint z) {
+    const plint xe = std::min<plint>(std::max<plint>(x, -1), nx) + 1;
+    return ((size_t)xe * ny + (size_t)src(y, ny, L->per.p[1])) * nz + (size_t)src(z, nz, L->per.p[2]);
+  };
   auto write_raw = [&](const string &name, int C, const vector<float> &out) {
     hsize_t dim[4] = {Nz, Ny, Nx, (hsize_t)C}, chunk[4] = {std::min<hsize_t>(1000, Nz), std::min<hsize_t>(1000, Ny), std::min<hsize_t>(1000, Nx), (hsize_t)C};
     hid_t sid = H5Screate_simple(4, dim, NULL), pl = H5Pcreate(H5P_DATASET_CREATE);
@@ -170,37 +210,42 @@ inline void writeFluidField_HDF5(HemoCell &h, const string &dir) {
     H5Dwrite(did, H5T_NATIVE_FLOAT, H5S_ALL, H5S_ALL, H5P_DEFAULT, out.data());
     H5Dclose(did); H5Pclose(pl); H5Sclose(sid);
   };
-  auto write4 = [&](const string &name, int C, const std::function<float(size_t, int)> &val) {
+  auto write4 = [&](const string &name, int C, const std::function<float(size_t, int)> &val) {   // val(extended index, component)
     vector<float> out((size_t)(Nx * Ny * Nz) * C); size_t o = 0;
     for (plint z = -1; z <= nz; z++) for (plint y = -1; y <= ny; y++) for (plint x = -1; x <= nx; x++) {
-      const size_t k = ((size_t)src(x, nx, L->per.p[0] && L->world == 1) * ny + src(y, ny, L->per.p[1])) * nz + src(z, nz, L->per.p[2]);   // a slab's x-envelope repeats its face
+      const size_t k = node_of(x, y, z);
       for (int cidx = 0; cidx < C; cidx++) out[o++] = val(k, cidx);
     }
     write_raw(name, C, out);
   };
-  const size_t xoff = (size_t)x0 * ny * nz;
-  auto is_bb = [&](size_t k) { return !L->bounce_back.empty() && L->bounce_back[k + xoff] != 0; };
   vector<double> pi;   // off-equilibrium momentum flux, fetched once if a stress or strain-rate field is asked for
-  auto need_pi = [&]() { if (pi.empty()) { pi.resize(6 * nn); hc_check(hcl_download_pi_neq(d, pi.data()), "hcl_download_pi_neq"); } };
-  // source node of output node (x, y, z), each in -1 .. n: the envelope repeats the face (or the periodic image)
-  auto node_of = [&](plint x, plint y, plint z) { return ((size_t)src(x, nx, L->per.p[0] && L->world == 1) * ny + src(y, ny, L->per.p[1])) * nz + src(z, nz, L->per.p[2]); };
+  auto need_pi = [&]() {
+    if (!pi.empty()) return;
+    vector<double> p0(6 * nn);
+    hc_check(hcl_download_pi_neq(d, p0.data()), "hcl_download_pi_neq");
+    pi.assign(6 * ne, 0.0); std::copy(p0.begin(), p0.end(), pi.begin() + 6 * plane);
+    fill_ends(pi, 6);
+  };
   for (int var : h.fluidOutputs) {
     if (var == OUTPUT_VELOCITY) write4("Velocity", 3, [&](size_t k, int cidx) { return (float)(u[3 * k + cidx] * (si ? Parameters::dx / Parameters::dt : 1.0)); });
     else if (var == OUTPUT_FORCE) {   // the external field as the driver left it (io/FluidHdf5IO.hh:240-262)
       const auto ext = L->external_now();
-      write4("Force", 3, [&](size_t k, int cidx) { return (float)(ext.at(x0 + (plint)(k / ((size_t)ny * nz)), (plint)(k / (size_t)nz % (size_t)ny), (plint)(k % (size_t)nz))[cidx] * (si ? Parameters::df : 1.0)); });
+      write4("Force", 3, [&](size_t k, int cidx) {
+        const plint xe = (plint)(k / plane) - 1, g = gx(xe) >= 0 ? gx(xe) : gx(xe < 0 ? 0 : nx - 1);
+        return (float)(ext.at(g, (plint)(k / (size_t)nz % (size_t)ny), (plint)(k % (size_t)nz))[cidx] * (si ? Parameters::df : 1.0));
+      });
     }
     else if (var == OUTPUT_DENSITY) write4("Density", 1, [&](size_t k, int) { return (float)(rho[k] * (si ? Parameters::df / (Parameters::dx * Parameters::dx) : 1.0)); });
-    else if (var == OUTPUT_BOUNDARY) write4("Boundary", 1, [&](size_t k, int) { return L->mask[k + xoff] ? 1.f : 0.f; });
+    else if (var == OUTPUT_BOUNDARY) write4("Boundary", 1, [&](size_t k, int) { return maskx[k] ? 1.f : 0.f; });
     else if (var == OUTPUT_OMEGA)   // getDynamics().getOmega(), scaled like a stress in SI as the reference does (io/FluidHdf5IO.hh:352-372); a BounceBack node has none
-      write4("Omega", 1, [&](size_t k, int) { return (float)((is_bb(k) ? 0.0 : (double)L->omega) * (si ? Parameters::df / (Parameters::dx * Parameters::dx) : 1.0)); });
+      write4("Omega", 1, [&](size_t k, int) { return (float)((bbx[k] ? 0.0 : (double)L->omega) * (si ? Parameters::df / (Parameters::dx * Parameters::dx) : 1.0)); });
     else if (var == OUTPUT_SHEAR_STRESS) {   // Cell::computeShearStress (io/FluidHdf5IO.hh:404-432): (omega/2 - 1) PiNeq in the bulk, zero on BounceBack nodes
       need_pi();
       const double pre = 0.5 * (double)L->omega - 1.0;
-      write4("ShearStress", 6, [&](size_t k, int cidx) { return (float)(is_bb(k) ? 0.0 : pre * pi[6 * k + cidx] * (si ? Parameters::df / (Parameters::dx * Parameters::dx) : 1.0)); });
+      write4("ShearStress", 6, [&](size_t k, int cidx) { return (float)(bbx[k] ? 0.0 : pre * pi[6 * k + cidx] * (si ? Parameters::df / (Parameters::dx * Parameters::dx) : 1.0)); });
     } else if (var == OUTPUT_STRAIN_RATE) {   // computeStrainRateFromStress (io/FluidHdf5IO.hh:497-552): -omega / (2 cs2 rho) PiNeq
       need_pi();
-      write4("StrainRate", 6, [&](size_t k, int cidx) { return (float)(is_bb(k) ? 0.0 : -1.5 * (double)L->omega / rho[k] * pi[6 * k + cidx] * (si ? 1.0 / Parameters::dt : 1.0)); });
+      write4("StrainRate", 6, [&](size_t k, int cidx) { return (float)(bbx[k] ? 0.0 : -1.5 * (double)L->omega / rho[k] * pi[6 * k + cidx] * (si ? 1.0 / Parameters::dt : 1.0)); });
     } else if (var == OUTPUT_SHEAR_RATE) {   // central differences of computeVelocity (io/FluidHdf5IO.hh:434-495); row a*3+b = d u_a / d x_b
       vector<float> out((size_t)(Nx * Ny * Nz) * 9); size_t o = 0;
       for (plint z = -1; z <= nz; z++) for (plint y = -1; y <= ny; y++) for (plint x = -1; x <= nx; x++) {

@@ -1,7 +1,9 @@
 // Every fluid output variable of io/FluidHdf5IO.hh:139-199 on a small pipe with one RBC, written once after the flow has
 // settled: tests/test_gpu_compat_driver.py checks the datasets against each other (shear rate = central differences of the
 // velocity dataset, strain rate = its symmetric part, stress = 2 mu strain rate, ...).
+#ifndef HEMOCELL_COMPAT_MAIN
 #define HEMOCELL_COMPAT_MAIN
+#endif
 #include "hemocell.h"
 #include "rbcHighOrderModel.h"
 
@@ -12,7 +14,7 @@ int main(int argc, char *argv[]) {
   HemoCell hemocell(argv[1], argc, argv);
   Config *cfg = hemocell.cfg;
   param::lbm_base_parameters(*cfg);
-  const plint nx = 64, ny = 34, nz = 34;
+  const plint nx = 96, ny = 34, nz = 34;   // two slabs of 48 planes when started as two ranks
   std::unique_ptr<MultiScalarField3D<int>> flagMatrix;
   std::unique_ptr<VoxelizedDomain3D<T>> voxelizedDomain;
   getFlagMatrixCylinder(nx, ny, nz, voxelizedDomain, flagMatrix);

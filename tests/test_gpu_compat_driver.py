@@ -185,8 +185,8 @@ def test_every_fluid_output_variable(tmp_path, gpu):
     for name, c in (("Velocity", 3), ("Density", 1), ("Force", 3), ("Boundary", 1), ("Omega", 1), ("ShearStress", 6), ("ShearRate", 9), ("StrainRate", 6),
                     ("CellDensity_RBC", 1), ("BindingSites", 1), ("InteriorPoints", 1)):
         seg = hdr[hdr.index('DATASET "%s"' % name):][:300]
-        assert "( 36, 36, 66, %d )" % c in seg, (name, seg)
-    N = (36, 36, 66)
+        assert "( 36, 36, 98, %d )" % c in seg, (name, seg)
+    N = (36, 36, 98)
     vel = _h5_array(f, "Velocity").reshape(N + (3,))
     bnd = _h5_array(f, "Boundary").reshape(N)
     umax = vel[..., 0].max() * dt / dx
@@ -203,7 +203,7 @@ def test_every_fluid_output_variable(tmp_path, gpu):
     st = _h5_array(f, "StrainRate").reshape(N + (6,))
     sym = 0.5 * (sr + np.swapaxes(sr, -1, -2))
     zz, yy = np.meshgrid(np.arange(36) - 1 - 16.5, np.arange(36) - 1 - 16.5, indexing="ij")
-    bulk = (np.sqrt(zz ** 2 + yy ** 2) < 12.5)[:, :, None] & (np.arange(66)[None, None, :] > 40) & (np.arange(66)[None, None, :] < 60)
+    bulk = (np.sqrt(zz ** 2 + yy ** 2) < 12.5)[:, :, None] & (np.arange(98)[None, None, :] > 56) & (np.arange(98)[None, None, :] < 90)
     scale = np.abs(sym[bulk]).max()
     for k, (a, b) in enumerate(((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))):
         assert np.abs(st[..., k] - sym[..., a, b])[bulk].max() < 0.03 * scale, (k, np.abs(st[..., k] - sym[..., a, b])[bulk].max(), scale)
@@ -224,6 +224,29 @@ def test_every_fluid_output_variable(tmp_path, gpu):
     zs, ys, xs = np.nonzero(cd)
     assert 4 < xs.min() and xs.max() < 30 and 5 < ys.min() and ys.max() < 30            # around x = 16 (+ the few steps it drifted), on the axis
     assert (_h5_array(f, "BindingSites") == 0).all() and (_h5_array(f, "InteriorPoints") == 0).all()
+    # ---- the same driver as two ranks (two x-slabs of 48 planes): every block's file carries its neighbour's face plane in the
+    # one-node envelope, so the two files put side by side are the one-rank file, gradients across the slab face included
+    d2 = str(tmp_path / "case2"); shutil.copytree(os.path.join(ROOT, "tests", "golden", "shear_case"), d2)
+    for fn in os.listdir(d2):
+        os.chmod(os.path.join(d2, fn), 0o644)
+    open(os.path.join(d2, "RBC.pos"), "w").write("1\n8.0 8.25 8.25 0 0 0\n")
+    port = str(34000 + os.getpid() % 20000)
+    procs = []
+    for rk in range(2):
+        env = dict(os.environ, OMPI_COMM_WORLD_RANK=str(rk), OMPI_COMM_WORLD_SIZE="2", OMPI_COMM_WORLD_LOCAL_RANK=str(rk), HEMOCELL_PORT=port, HEMOCELL_TRANSPORT="tcp",
+                   HEMOCELL_COMM_TIMEOUT="120")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        procs.append(subprocess.Popen([exe, "config.xml"], cwd=d2, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs[0][-2000:] + outs[1][-2000:]
+    halves = [os.path.join(d2, "tmp", "hdf5", "000000000010", "Fluid.000000000010.p.%d.h5" % rk) for rk in range(2)]
+    for name, c in (("Velocity", 3), ("Density", 1), ("ShearRate", 9), ("StrainRate", 6), ("ShearStress", 6), ("Boundary", 1)):
+        one = _h5_array(f, name).reshape(N + (c,))
+        two = [_h5_array(hf, name).reshape((36, 36, 50, c)) for hf in halves]
+        scale = np.abs(one).max()
+        for rk in range(2):   # all 50 planes of a block's file, envelope planes included, against planes 48 rk .. 48 rk + 49 of the whole
+            assert np.abs(two[rk] - one[:, :, 48 * rk:48 * rk + 50]).max() <= 2e-5 * scale, (name, rk)
 
 
 def test_moving_wall_couette_vs_oracle(orc, gpu):

@@ -494,6 +494,16 @@ def test_reference_pipeflow_driver_two_ranks_reproduce_the_one_rank_log(tmp_path
             dump = subprocess.run(["/opt/conda/bin/h5dump", "-a", "/numberOfParticles", rbc], capture_output=True, text=True).stdout
             n += int(dump[dump.index("(0):") + 4:].split()[0])
         assert n == 35 * 642                                           # every RBC is written by exactly one rank
+    # the CSV summaries are gathered on rank 0 (io/writeCellInfoCSV.cpp:45): same cells, same numbers as the one-rank run
+    for name in sorted(os.listdir(str(one / "tmp" / "csv"))):
+        h1, c1 = _csv(str(one / "tmp" / "csv" / name)); h2, c2 = _csv(str(work / "tmp" / "csv" / name))
+        assert h1 == h2 and c1.shape == c2.shape
+        c1, c2 = c1[np.argsort(c1[:, 6])], c2[np.argsort(c2[:, 6])]
+        cols = [0, 1, 2, 3, 4, 6, 7, 8, 9, 10]                         # all but atomic_block
+        Lx = 103 * 0.5e-6
+        dxp = (c2[:, 0] - c1[:, 0] + Lx / 2) % Lx - Lx / 2              # a centre next to the periodic seam may be reported on either side of it
+        assert np.abs(dxp).max() < 1e-9
+        assert np.allclose(c1[:, cols[1:]], c2[:, cols[1:]], rtol=1e-4, atol=1e-12), name
 
 
 def test_reference_stretchcell_driver_passes_its_ci_sanity(tmp_path, gpu):

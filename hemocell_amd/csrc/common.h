@@ -136,5 +136,6 @@ namespace hcs {
 int iterate_slab(hc_lattice *L, hc_cells *C, long *iter, int n, int particle_timescale, int force_limit);
 int collide_stream_slab(hc_lattice *L, int nsteps);
 void lattice_destroyed(hc_lattice *L);
+void halos_stale(hc_lattice *L);   // the populations were replaced from outside: the halo planes have to be fetched again
 void set_overlap(int on);
 }

@@ -19,6 +19,7 @@
 // Arithmetic follows oracle/hemo_oracle.c operation for operation (the library
 // is built with -ffp-contract=off) so that fluid-only runs are bit-identical.
 #include "common.h"
+#include "comm.h"
 #include <algorithm>
 
 using namespace hc;
@@ -266,7 +267,9 @@ __global__ void download_kernel(LatArgs a, double *aos) {
 }
 
 // inverse of download: P(y,i) = S(y+c_i, i) (0 if the target lies outside)
-__global__ void upload_kernel(LatArgs a, const double *aos) {
+// lo_ok / hi_ok: the post-stream state of the plane below / above the slab is in aos as well (planes -1 and nx of the host
+// numbering, fetched from the neighbouring ranks)
+__global__ void upload_kernel(LatArgs a, const double *aos, int lo_ok, int hi_ok) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= a.plane) return;
   const int x = a.x_begin + blockIdx.y;
@@ -278,8 +281,8 @@ __global__ void upload_kernel(LatArgs a, const double *aos) {
 #define M(Q, CX, CY, CZ)                                                                  \
   {                                                                                       \
     bool ok; long off = dst_off<CX, CY, CZ>(nl, ok);                                      \
-    /* without x wrap the +-x neighbour of a face plane is a halo plane: outside */       \
-    if (!a.wrap_x && ((CX == 1 && x == a.nx - 1) || (CX == -1 && x == 0))) ok = false;    \
+    /* without x wrap the +-x neighbour of a face plane belongs to the neighbouring rank, or lies outside the domain */ \
+    if (!a.wrap_x && ((CX == 1 && x == a.nx - 1 && !hi_ok) || (CX == -1 && x == 0 && !lo_ok))) ok = false; \
     a.fout[(long)Q * a.qs + node] = ok ? aos[(bulk + off) * HC_Q + Q] : 0.0;            \
   }
   FOR_Q(M)
@@ -764,12 +767,26 @@ int hcl_download_populations(hc_lattice *L, double *f_aos) {
 
 int hcl_upload_populations(hc_lattice *L, const double *f_aos) {
   HC_REQUIRE(L && f_aos, "hcl_upload_populations: null pointer");
-  const size_t nd = (size_t)L->nx * L->plane * HC_Q;
-  int rc = ensure_scratch(L, nd); if (rc != HC_OK) return rc;
-  HC_HIP(hipMemcpyAsync(L->scratch, f_aos, nd * sizeof(double), hipMemcpyHostToDevice, hc::stream()));
+  const size_t np = (size_t)L->plane * HC_Q, nd = (size_t)L->nx * np;
+  int rc = ensure_scratch(L, nd + 2 * np); if (rc != HC_OK) return rc;
+  double *bulk = L->scratch + np;   // scratch: plane -1, the nx planes of the slab, plane nx
+  HC_HIP(hipMemcpyAsync(bulk, f_aos, nd * sizeof(double), hipMemcpyHostToDevice, hc::stream()));
+  int lo_ok = 0, hi_ok = 0;
+  if (L->n_slabs > 1) {
+    // The stored value of a face node in a direction that crosses the face is the post-stream value of the NEIGHBOUR's first
+    // plane: every rank hands its face planes to its neighbours (collective: all ranks of the run upload together, as
+    // HemoCell::loadCheckPoint does)
+    HC_REQUIRE(hcm::active(), "hcl_upload_populations: a slab of a multi-rank run needs the ranks connected (hc_comm_init) -- the call is collective");
+    int lo, hi; hcm::neighbours(L->periodic[0] != 0, lo, hi);
+    lo_ok = lo >= 0; hi_ok = hi >= 0;
+    rc = hcm::exchange(hc::stream(), L->periodic[0] != 0, bulk, np * sizeof(double), bulk + (size_t)(L->nx - 1) * np, np * sizeof(double), L->scratch, np * sizeof(double),
+                       bulk + nd, np * sizeof(double));
+    if (rc != HC_OK) return rc;
+    hcs::halos_stale(L);
+  }
   LatArgs a = make_args(L);
   a.fout = L->f[L->cur];
-  hipLaunchKernelGGL(upload_kernel, plane_grid(L, L->nx), dim3(256), 0, hc::stream(), a, (const double *)L->scratch);
+  hipLaunchKernelGGL(upload_kernel, plane_grid(L, L->nx), dim3(256), 0, hc::stream(), a, (const double *)bulk, lo_ok, hi_ok);
   HC_HIP(hipGetLastError());
   HC_HIP(hipStreamSynchronize(hc::stream()));
   return HC_OK;

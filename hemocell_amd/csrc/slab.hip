@@ -427,6 +427,11 @@ int collide_stream_slab(hc_lattice *L, int nsteps) { return run(L, nullptr, null
 
 void set_overlap(int on) { g_slab_overlap = on != 0; }
 
+void halos_stale(hc_lattice *L) {
+  auto it = g_slabs.find(L);
+  if (it != g_slabs.end()) { it->second->halo_fresh = false; it->second->pending_width = 0; }
+}
+
 void lattice_destroyed(hc_lattice *L) {
   auto it = g_slabs.find(L);
   if (it == g_slabs.end()) return;

@@ -150,7 +150,7 @@ int hcl_step_end(hc_lattice *L);
 /* populations in the reference's own layout: AoS [node][19], node = z + nz*(y + ny*x), values f_i - t_i
  * as Palabos stores them (post-stream state, i.e. what Cell::operator[] returns after collideAndStream) */
 int hcl_download_populations(hc_lattice *L, double *f_aos);
-int hcl_upload_populations(hc_lattice *L, const double *f_aos);
+int hcl_upload_populations(hc_lattice *L, const double *f_aos);   /* on a slab of a multi-rank run: collective (the ranks exchange their face planes) */
 /* rho[n] and u[n][3] = Cell::computeVelocity (j/rho + F/2), local bulk nodes */
 int hcl_download_rho_u(hc_lattice *L, double *rho, double *u);
 /* pi[n][6] = the off-equilibrium momentum flux of the post-stream populations (xx, xy, xz, yy, yz, zz), the quantity

@@ -249,6 +249,43 @@ def test_every_fluid_output_variable(tmp_path, gpu):
             assert np.abs(two[rk] - one[:, :, 48 * rk:48 * rk + 50]).max() <= 2e-5 * scale, (name, rk)
 
 
+def _launch_ranks(exe, args, cwd, world, salt=0):
+    """a driver binary started as `world` processes the way mpirun would start them (rank and size in the environment); the
+    ranks share the one GPU of the test box, so the data plane is the host-staged one"""
+    port = str(30000 + (os.getpid() * 7 + salt * 131) % 20000)
+    procs = []
+    for rk in range(world):
+        env = dict(os.environ, OMPI_COMM_WORLD_RANK=str(rk), OMPI_COMM_WORLD_SIZE=str(world), OMPI_COMM_WORLD_LOCAL_RANK=str(rk), HEMOCELL_PORT=port,
+                   HEMOCELL_TRANSPORT="tcp", HEMOCELL_COMM_TIMEOUT="120")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        procs.append(subprocess.Popen([exe] + args, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert [p.returncode for p in procs] == [0] * world, "".join(o[-1500:] for o in outs)
+    return outs
+
+
+def test_two_rank_checkpoint_and_resume(tmp_path, gpu):
+    """core/hemoCellFields.cpp:240-319 with two ranks: every rank dumps its block (checkpoint.<rank>.bin), a restart of two ranks
+    from the iteration-200 dump prints the remaining statistics of the uninterrupted two-rank run, digit for digit"""
+    exe = _build(tmp_path, "examples/pipe/pipe_synthetic.cpp")
+    case = str(tmp_path / "pipe2"); os.makedirs(case)
+    for f in ("config.xml", "RBC.xml", "PLT.xml", "RBC.pos", "PLT.pos"):
+        shutil.copy(os.path.join(ROOT, "examples", "pipe", f), case)
+    full = _launch_ranks(exe, ["config.xml"], case, 2, salt=1)
+    stat_full = [l for l in full[0].splitlines() if l.startswith("STAT")]
+    assert len(stat_full) == 4
+    assert [l for l in full[1].splitlines() if l.startswith("STAT")] == stat_full      # the statistics are reduced over the ranks: both print the same
+    ck = os.path.join(case, "tmp_pipe", "checkpoint")
+    for f in ("checkpoint.0.bin", "checkpoint.1.bin", "checkpoint.xml"):
+        assert os.path.exists(os.path.join(ck, f + ".old")), f
+        os.replace(os.path.join(ck, f + ".old"), os.path.join(ck, f))        # the iteration-200 dump
+    again = _launch_ranks(exe, ["tmp_pipe/checkpoint/checkpoint.xml"], case, 2, salt=2)
+    stat_again = [l for l in again[0].splitlines() if l.startswith("STAT")]
+    assert stat_again == stat_full[2:], (stat_again, stat_full)
+    assert "resumed at iteration 200" in open(os.path.join(case, "tmp_pipe", "log", "logfile.0")).read()
+
+
 def test_moving_wall_couette_vs_oracle(orc, gpu):
     """helper/hemocellInit.hh:71-86 (oneCellShear): top/bottom walls moving in +-x, x and y periodic.  GPU vs
     oracle bit for bit, and the steady profile is linear with the imposed shear rate."""

@@ -458,6 +458,25 @@ def test_reference_bent_microvessel_driver(tmp_path, gpu):
     assert len(visc) == 2 and all(0.9 < v < 1.3 for v in visc), visc
 
 
+def test_reference_vasoconstriction_driver(tmp_path, gpu):
+    """cases/vasoconstriction_pipe/vasoconstriction_pipe.cpp: a pipe with a narrowed stretch from a DomainFunctional3D, RBC + PLT"""
+    work, out = _run_short(tmp_path, "vasoconstriction_pipe", 400, 200)
+    cells = [l for l in out if "# of cells" in l]
+    assert len(cells) == 2 and len(set(cells)) == 1 and int(cells[0].split("# of cells:")[1].split()[0]) > 300
+    visc = [float(l.split("viscosity:")[1]) for l in out if "viscosity:" in l]
+    assert len(visc) >= 2 and all(0.9 < v < 1.3 for v in visc[-2:]), visc
+
+
+def test_reference_stentflow_driver(tmp_path, gpu):
+    """cases/stentflow/stentflow.cpp ships no .pos files: the driver warns and runs the fluid alone through its stented pipe"""
+    work, out = _run_short(tmp_path, "stentflow", 400, 200)
+    assert any("does not exist" in l for l in out)                       # "*** WARNING! particle positions input file ... does not exist!"
+    cells = [l for l in out if "# of cells" in l]
+    assert len(cells) == 2 and all("# of cells: 0 " in l for l in cells)
+    visc = [float(l.split("viscosity:")[1]) for l in out if "viscosity:" in l]
+    assert all(0.9 < v < 1.1 for v in visc[-2:]), visc
+
+
 def _cut(line, *spec):
     """cut -d<delim> -f<n> chains of the CI scripts"""
     for delim, n in spec:

@@ -477,6 +477,16 @@ def test_reference_stentflow_driver(tmp_path, gpu):
     assert all(0.9 < v < 1.1 for v in visc[-2:]), visc
 
 
+def test_reference_atherosclerosis_driver(tmp_path, gpu):
+    """cases/atherosclerosis/atherosclerosis.cpp: a channel with a plaque from a DomainFunctional3D.  The .pos files the case ships
+    announce 0 cells (its suspensions live under initial_states/); the fixtures keep that first line only"""
+    work, out = _run_short(tmp_path, "atherosclerosis", 200, 100)
+    assert "(readPositionsBloodCells) Particle count in file (RBC): 0." in out
+    vmax = [float(l.split("max.:")[1].split()[0]) for l in out if "Velocity  -" in l]
+    assert len(vmax) == 2 and 0 < vmax[0] < vmax[1] < 0.1                    # the driven flow is still accelerating
+    assert out[-1].strip() == "(main) Simulation finished :)"
+
+
 def _cut(line, *spec):
     """cut -d<delim> -f<n> chains of the CI scripts"""
     for delim, n in spec:

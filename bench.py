@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--periodic-box", action="store_true",
                     help="cases/performance_testing geometry: fully periodic box, no walls, tau = 1, body force on all axes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-target-512", action="store_true", help="skip the second measurement of the default run (north_star's 512^3 pipe, 25 steps)")
     ap.add_argument("--no-kernel-profile", action="store_true", help="A/B: no per-kernel hipEvent brackets in the timed region (roofline fields are then empty)")
     ap.add_argument("--plane-padding", choices=["auto", "on", "off"], default="auto", help="A/B: padded x-plane stride (auto: planes that are a multiple of 1 MiB)")
     ap.add_argument("--no-overlap", action="store_true",
@@ -67,8 +68,11 @@ def usable_cores():
 
 
 def cpu_baseline(args, budget_s):
-    """the oracle (CPU restatement, "kind": "port") on a bounded sample of the same workload: a
-    64x128x128 pipe at the same hematocrit and cadences, on the host cores this process may use (OpenMP)."""
+    """the oracle (CPU restatement, "kind": "port") on the metric's OWN configuration -- the whole pipe of the GPU run, same
+    cells, same cadences -- on the host cores this process may use (OpenMP over collide-stream, IBM and mechanics).
+    Bounded sample: the first iterations of the run (a whole cadence window of 20 where the budget allows).  Two figures:
+    `value` with the collide-stream as ONE pass over the lattice (orc_collide_stream_fused: collide in registers, push),
+    `two_pass` with the oracle's literal collide-then-stream (copy, collide in place, gather) -- same arithmetic, same bits."""
     import ctypes as C
 
     from hemocell_amd.packing import pack_pipe_rbc
@@ -76,39 +80,53 @@ def cpu_baseline(args, budget_s):
     from oracle import oracle as O
 
     orc = O.load()
-    nx, ny, nz = 64, 128, 128
+    nx, ny, nz = args.nx, args.ny, args.nz
     cores = usable_cores()
     P = O.make_params(orc)
     mask, R = pipe_mask(nx, ny, nz)
-    L = O.OracleLattice(orc, nx, ny, nz, (1, 0, 0), 1.0 / P.tau)
-    L.set_mask(mask); L.init_equilibrium(); L.set_threads(cores)
-    S = orc.orc_sim_create(L.ptr, C.byref(P))
-    T = O.make_rbc(orc, P); T.contents.timescale = 20
-    orc.orc_sim_add_type(S, T)
-    S.contents.particle_velocity_timescale = 5
-    ncell = 0
-    if not args.fluid_only:
-        centres, angles = pack_pipe_rbc(nx, ny, nz, args.hematocrit)
+    centres, angles = ([], []) if args.fluid_only else pack_pipe_rbc(nx, ny, nz, args.hematocrit)
+    F = body_force(ny, P.nu_lbm)
+    legs = {}
+    for name, fused, share in (("fused", 1, 0.35), ("two_pass", 0, 0.65)):
+        L = O.OracleLattice(orc, nx, ny, nz, (1, 0, 0), 1.0 / P.tau)
+        L.set_threads(cores)
+        L.set_mask(mask); L.init_equilibrium()
+        L.ptr.contents.fused = fused
+        S = orc.orc_sim_create(L.ptr, C.byref(P))
+        T = O.make_rbc(orc, P); T.contents.timescale = 20
+        orc.orc_sim_add_type(S, T)
+        S.contents.particle_velocity_timescale = 5
+        ncell = 0
         for c, a in zip(centres, angles):
             ar = np.array(a) * (3.14159265358979323846 / 180.0) * -1.0
             ncell += orc.orc_sim_add_cell(S, 0, O.dptr(np.ascontiguousarray(c)), O.dptr(ar), 0.0)
-    F = body_force(ny, P.nu_lbm)
-    L.set_force_uniform(F)
-    for d in range(3):
-        S.contents.body_force[d] = F[d]
-    orc.orc_sim_mechanics(S, 1)
-    orc.orc_sim_iterate(S)  # warm
-    t0 = time.perf_counter(); steps = 0
-    while time.perf_counter() - t0 < budget_s and steps < 2000:
-        orc.orc_sim_iterate(S); steps += 1
-    dt = time.perf_counter() - t0
-    nverts = S.contents.np
-    return {"value": nx * ny * nz * steps / dt / 1e6, "unit": "MLUPS", "cores": cores, "kind": "port",
-            "mlups_per_core": nx * ny * nz * steps / dt / 1e6 / cores,
-            "sample_nodes_over_gpu_nodes": nx * ny * nz / float(args.nx * args.ny * args.nz),
-            "sample": "oracle (oracle/hemo_oracle.c, OpenMP collide-stream, IBM and mechanics), pipe %dx%dx%d, %d RBC "
-                      "(%d vertices), %d steps in %.1f s" % (nx, ny, nz, ncell, nverts, steps, dt),
-            "vertex_updates_per_s": nverts * steps / dt}
+        L.set_force_uniform(F)
+        for d in range(3):
+            S.contents.body_force[d] = F[d]
+        orc.orc_sim_mechanics(S, 1)
+        orc.orc_sim_iterate(S)      # iteration 0 untimed: first touch of the second population buffer and of the stencil arrays
+        t0 = time.perf_counter(); steps = 0
+        # whole cadence windows of 5 iterations (one velocity update each); at least one, at most 20 iterations
+        while steps < 20 and (steps < 5 or (time.perf_counter() - t0) * (steps + 5) / steps < budget_s * share):
+            for _ in range(5):
+                orc.orc_sim_iterate(S)
+            steps += 5
+        dt = time.perf_counter() - t0
+        nverts = S.contents.np
+        legs[name] = {"mlups": nx * ny * nz * steps / dt / 1e6, "steps": steps, "seconds": dt,
+                      "vertex_updates_per_s": nverts * steps / dt}
+        orc.orc_sim_destroy(S); L.destroy()
+    best = legs["fused"]
+    return {"value": best["mlups"], "unit": "MLUPS", "cores": cores, "kind": "port",
+            "mlups_per_core": best["mlups"] / cores,
+            "sample_nodes_over_gpu_nodes": 1.0,
+            "sample": "oracle (oracle/hemo_oracle.c, OpenMP collide-stream, IBM and mechanics) on the metric's own workload: pipe "
+                      "%dx%dx%d, %d RBC (%d vertices), iterations 1..%d (velocity updates every 5th, mechanics every 20th) in %.1f s with the "
+                      "one-pass collide-stream; %d iterations in %.1f s with the oracle's literal two-pass form"
+                      % (nx, ny, nz, ncell, nverts, best["steps"], best["seconds"], legs["two_pass"]["steps"], legs["two_pass"]["seconds"]),
+            "vertex_updates_per_s": best["vertex_updates_per_s"],
+            "two_pass": {"value": legs["two_pass"]["mlups"], "unit": "MLUPS", "mlups_per_core": legs["two_pass"]["mlups"] / cores,
+                         "vertex_updates_per_s": legs["two_pass"]["vertex_updates_per_s"]}}
 
 
 def body_force(ny, nu_lbm, Re=0.5):
@@ -116,6 +134,90 @@ def body_force(ny, nu_lbm, Re=0.5):
     R = (ny - 2) / 2.0
     u_max = Re * nu_lbm / (2 * R)
     return (8.0 * nu_lbm * (u_max * 0.5) / (R * R), 0.0, 0.0)
+
+
+def make_workload(args, nx, ny, nz, rank, world):
+    """the synthetic pipeflow of the metric: lattice, walls, driving force, cells placed and their initial forces evaluated;
+    everything resident in HBM when this returns.  -> (parameters, SlabRunner, pipe radius, distinct cells)"""
+    from hemocell_amd import host
+    from hemocell_amd.packing import pack_pipe_rbc
+    from hemocell_amd.slab import SlabRunner
+
+    # examples/pipeflow/config.xml:25-28: dx 5e-7, dt 1e-7, nuP 1.1e-6 -> tau 1.82; performance_testing: dt = -1 -> tau = 1
+    P = host.base_parameters(dt=-1.0) if args.periodic_box else host.base_parameters()
+    nxg = nx * world
+    # every-step deletion semantics (core/hemoCellParticleField.cpp:566-588): the check lives in the advance kernel
+    runner = SlabRunner(nx_local=nx, ny=ny, nz=nz, rank=rank, world=world, P=P,
+                        periodic=(True, True, True) if args.periodic_box else (True, False, False),
+                        particle_timescale=5, material_timescale=20,
+                        deletion_check_every=1, fluid_only=args.fluid_only or args.periodic_box)
+    mask, R = host.pipe_mask(nxg, ny, nz)
+    if args.periodic_box:
+        mask[:] = 0
+        args.fluid_only = True
+    runner.define_bounce_back(mask)
+    runner.lattice.latticeEquilibrium(1.0, (0, 0, 0))
+    bf = body_force(ny, P.nu_lbm)
+    runner.lattice.setExternalVector((bf[0], bf[0], bf[0]) if args.periodic_box else bf)
+    n_cells = 0
+    if not args.fluid_only:
+        rbc = host.CellType.rbc(P)
+        runner.add_cell_type(rbc)
+        centres, angles = pack_pipe_rbc(nxg, ny, nz, args.hematocrit)
+        runner.load_cells(0, centres, angles)
+        if args.plt_ratio > 0:
+            # platelets (66 vertices, 2.5 x 1.1 um discs) in the gaps of the RBC grid: half a pitch off in x and z
+            plt_t = runner.add_cell_type(host.CellType.plt(P))
+            pick = np.arange(0, len(centres), max(1, int(round(1.0 / args.plt_ratio))))
+            pc = centres[pick] + np.array([9.5, 0.0, 0.0]); pc[:, 2] += np.where(pc[:, 2] > nz / 2, -4.6, 4.6)
+            pa = np.tile(np.array([90.0, 0.0, 0.0]), (len(pc), 1))
+            runner.load_cells(plt_t, pc, pa)
+        n_cells = int(runner.sync_placement().sum())     # distinct cells over all slabs
+    runner.prepare()
+    return P, runner, R, n_cells
+
+
+def target_512(args, steps=25, warmup=5):
+    """north_star's target workload on the driver's clock: the 512^3 pipe at 10 % hematocrit on one GPU (>= 0.60 of the HBM-roofline
+    MLUPS asked for), measured like the headline: barrier + synchronise on both sides of `steps` whole iterations"""
+    from hemocell_amd import host
+
+    lib = host.capi.lib()
+    n = 512
+    P, runner, R, n_cells = make_workload(args, n, n, n, 0, 1)
+    nverts = runner.owned_vertices()
+    runner.run(warmup)
+    lib.hc_profile_reset(); lib.hc_profile_enable(1)
+    host.check(lib.hc_synchronize())
+    t0 = time.perf_counter()
+    runner.run(steps)
+    host.check(lib.hc_synchronize())
+    elapsed = time.perf_counter() - t0
+    lib.hc_profile_enable(0)
+    counts = np.zeros(3, dtype=np.int64)
+    host.check(lib.hcl_node_counts(runner.lattice.ptr, host.lptr(counts)))
+    prof = {}
+    for k in ("collide_stream", "collide_stream_alone", "collide_stream_beside", "ibm_spread", "ibm_interpolate", "advance", "mechanics"):
+        m2, n2 = C.c_double(), C.c_long()
+        host.check(lib.hc_profile_read(k.encode(), C.byref(m2), C.byref(n2)))
+        prof[k] = {"avg_ms": m2.value / max(n2.value, 1), "launches": n2.value}
+    nodes = n ** 3
+    bpn = runner.lattice.bytes_per_node()
+    mlups = nodes * steps / elapsed / 1e6
+    col = prof["collide_stream"]["avg_ms"]
+    out = {"workload": "pipe %dx%dx%d (R=%.0f), %d RBC (%d vertices), 10 %% Hct, same cadences as the headline" % (n, n, n, R, n_cells, nverts),
+           "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "mlups": mlups,
+           "mlups_fluid_nodes": int(counts[1]) * steps / elapsed / 1e6, "vertex_updates_per_s": nverts * steps / elapsed,
+           "fluid_node_fraction": int(counts[1]) / nodes, "active_node_fraction": int(counts[2]) / nodes,
+           # whole step: by the SURVEY 8(d) convention (353 B x every node of the box) and over the nodes the kernel visits
+           "whole_step_hbm_frac": mlups * 1e6 * bpn / 8.0e12,
+           "whole_step_hbm_frac_active_nodes": int(counts[2]) * steps / elapsed * bpn / 8.0e12,
+           # the collide kernel alone, over the nodes it visits (an upper bound of the bytes that move)
+           "collide_avg_ms": col, "collide_frac_active_nodes": int(counts[2]) * bpn / (col * 1e-3) / 8.0e12 if col > 0 else None,
+           "collide_frac_convention": nodes * bpn / (col * 1e-3) / 8.0e12 if col > 0 else None,
+           "kernel_avg_ms": prof, "target": "north_star: >= 0.60 of the HBM-roofline MLUPS on this workload at 1 GPU"}
+    runner.cells.destroy(); runner.lattice.destroy()
+    return out
 
 
 def launch_ranks(args):
@@ -148,8 +250,6 @@ def main():
         os.environ["HEMOCELL_TRANSPORT"] = args.transport
 
     from hemocell_amd import host, slab
-    from hemocell_amd.packing import pack_pipe_rbc
-    from hemocell_amd.slab import SlabRunner
 
     lib = host.capi.lib()
     if world > 1:
@@ -161,37 +261,8 @@ def main():
         host.check(lib.hc_set_overlap(0))
     host.check(lib.hc_debug_force_plane_padding({"auto": 0, "on": 1, "off": -1}[args.plane_padding]))
 
-    # examples/pipeflow/config.xml:25-28: dx 5e-7, dt 1e-7, nuP 1.1e-6 -> tau 1.82; performance_testing: dt = -1 -> tau = 1
-    P = host.base_parameters(dt=-1.0) if args.periodic_box else host.base_parameters()
+    P, runner, R, n_cells = make_workload(args, args.nx, args.ny, args.nz, rank, world)
     nxg = args.nx * world
-    # every-step deletion semantics (core/hemoCellParticleField.cpp:566-588): the check lives in the advance kernel
-    runner = SlabRunner(nx_local=args.nx, ny=args.ny, nz=args.nz, rank=rank, world=world, P=P,
-                        periodic=(True, True, True) if args.periodic_box else (True, False, False),
-                        particle_timescale=5, material_timescale=20,
-                        deletion_check_every=1, fluid_only=args.fluid_only or args.periodic_box)
-    mask, R = host.pipe_mask(nxg, args.ny, args.nz)
-    if args.periodic_box:
-        mask[:] = 0
-        args.fluid_only = True
-    runner.define_bounce_back(mask)
-    runner.lattice.latticeEquilibrium(1.0, (0, 0, 0))
-    bf = body_force(args.ny, P.nu_lbm)
-    runner.lattice.setExternalVector((bf[0], bf[0], bf[0]) if args.periodic_box else bf)
-    n_cells = 0
-    if not args.fluid_only:
-        rbc = host.CellType.rbc(P)
-        runner.add_cell_type(rbc)
-        centres, angles = pack_pipe_rbc(nxg, args.ny, args.nz, args.hematocrit)
-        runner.load_cells(0, centres, angles)
-        if args.plt_ratio > 0:
-            # platelets (66 vertices, 2.5 x 1.1 um discs) in the gaps of the RBC grid: half a pitch off in x and z
-            plt_t = runner.add_cell_type(host.CellType.plt(P))
-            pick = np.arange(0, len(centres), max(1, int(round(1.0 / args.plt_ratio))))
-            pc = centres[pick] + np.array([9.5, 0.0, 0.0]); pc[:, 2] += np.where(pc[:, 2] > args.nz / 2, -4.6, 4.6)
-            pa = np.tile(np.array([90.0, 0.0, 0.0]), (len(pc), 1))
-            runner.load_cells(plt_t, pc, pa)
-        n_cells = int(runner.sync_placement().sum())     # distinct cells over all slabs
-    runner.prepare()
     nverts_local = runner.owned_vertices()
 
     def barrier():
@@ -316,6 +387,13 @@ def main():
             out["slab_schedule"] = {"host_ms_per_step": host_ms_per_step, "header_wait_ms_per_velocity_update": header_wait_ms,
                                     "records_sent_rank0": sstats["cells_sent"], "copies_created_rank0": sstats["cells_new"],
                                     "copies_dropped_rank0": sstats["cells_dropped"]}
+        headline = (args.nx, args.ny, args.nz) == (256, 256, 256) and not args.fluid_only and abs(args.hematocrit - 0.10) < 1e-12 and args.plt_ratio == 0
+        if world == 1 and headline and not args.no_target_512:
+            # after the headline measurement, with its memory returned: north_star's target workload on the same clock
+            if runner.cells is not None:
+                runner.cells.destroy()
+            runner.lattice.destroy()
+            out["target_512"] = target_512(args)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         os.write(result_fd, (json.dumps(out) + "\n").encode())

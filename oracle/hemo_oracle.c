@@ -67,6 +67,7 @@ void orc_lattice_init_equilibrium(orc_lattice *L, double rho, const double u[3])
   double rhoBar = rho - 1.0;
   double j[3] = {rho * u[0], rho * u[1], rho * u[2]};
   double jSqr = j[0] * j[0] + j[1] * j[1] + j[2] * j[2];
+#pragma omp parallel for num_threads(L->nthreads) schedule(static) if (L->nthreads > 1)
   for (long k = 0; k < n; k++)
     for (int i = 0; i < ORC_Q; i++) L->f[k * ORC_Q + i] = L->mask[k] ? 0.0 : feq_bar(i, rhoBar, j, jSqr);
 }
@@ -163,6 +164,7 @@ static void collide_moving_wall(double *f, const double *uw) {
 void orc_collide_stream(orc_lattice *L) {
   const int nx = L->nx, ny = L->ny, nz = L->nz;
   const long n = (long)nx * ny * nz;
+  if (L->fused) { orc_collide_stream_fused(L); return; }
   memcpy(L->ftmp, L->f, (size_t)n * ORC_Q * sizeof(double));
 #ifdef _OPENMP
 #pragma omp parallel for num_threads(L->nthreads) schedule(static)
@@ -188,6 +190,59 @@ void orc_collide_stream(orc_lattice *L) {
           L->f[k * ORC_Q + i] = ok ? L->ftmp[(sz + (long)nz * (sy + (long)ny * sx)) * ORC_Q + i] : 0.0;
         }
       }
+}
+
+/* The same step in one pass: every node is collided in a local copy and its 19 post-collision values are pushed to
+ * the neighbours' slots of the second buffer (f_i(x+c_i) <- f*_i(x)); the buffers are then swapped.  Slots whose source
+ * lies outside a non-periodic face are set to 0 first, as above.  The operations on every value are those of
+ * orc_collide_stream in the same order, so the result is bit-identical (tests/test_oracle_pins.py); only the data
+ * movement differs (one read and one write of the populations instead of three of each). */
+void orc_collide_stream_fused(orc_lattice *L) {
+  const int nx = L->nx, ny = L->ny, nz = L->nz;
+  double *restrict src = L->f, *restrict dst = L->ftmp;
+  /* faces without a source (non-periodic axes): fBar = 0 for the populations that would come from outside */
+  for (int d = 0; d < 3; d++) {
+    if (L->periodic[d]) continue;
+    const int nd = d == 0 ? nx : d == 1 ? ny : nz;
+    for (int side = 0; side < 2; side++) {
+      const int at = side ? nd - 1 : 0;
+      if (nd == 1 && side) continue;
+      const int na = d == 0 ? ny : nx, nb = d == 2 ? ny : nz;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(L->nthreads) schedule(static) if (L->nthreads > 1)
+#endif
+      for (int a = 0; a < na; a++)
+        for (int b = 0; b < nb; b++) {
+          const int x = d == 0 ? at : a, y = d == 1 ? at : (d == 0 ? a : b), z = d == 2 ? at : b;
+          const long k = z + (long)nz * (y + (long)ny * x);
+          for (int i = 0; i < ORC_Q; i++) {
+            const int s = at - orc_c[i][d];
+            if (s < 0 || s >= nd) dst[k * ORC_Q + i] = 0.0;
+          }
+        }
+    }
+  }
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(L->nthreads) schedule(static)
+#endif
+  for (int x = 0; x < nx; x++)
+    for (int y = 0; y < ny; y++)
+      for (int z = 0; z < nz; z++) {
+        const long k = z + (long)nz * (y + (long)ny * x);
+        double f[ORC_Q];
+        for (int i = 0; i < ORC_Q; i++) f[i] = src[k * ORC_Q + i];
+        if (L->mask[k] >= 3) collide_moving_wall(f, L->wall_u[L->mask[k] - 3]);
+        else if (L->mask[k]) collide_bounce_back(f);
+        else collide_guo_bgk(f, L->force + 3 * k, L->omega);
+        for (int i = 0; i < ORC_Q; i++) {
+          int tx = x + orc_c[i][0], ty = y + orc_c[i][1], tz = z + orc_c[i][2];
+          if (tx < 0 || tx >= nx) { if (L->periodic[0]) tx = (tx + nx) % nx; else continue; }
+          if (ty < 0 || ty >= ny) { if (L->periodic[1]) ty = (ty + ny) % ny; else continue; }
+          if (tz < 0 || tz >= nz) { if (L->periodic[2]) tz = (tz + nz) % nz; else continue; }
+          dst[(tz + (long)nz * (ty + (long)ny * tx)) * ORC_Q + i] = f[i];
+        }
+      }
+  L->f = dst; L->ftmp = src;
 }
 
 /* ======================================================================== */

@@ -20,7 +20,8 @@ c_int_p = C.POINTER(C.c_int)
 class Lattice(C.Structure):
     _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("periodic", C.c_int * 3),
                 ("omega", C.c_double), ("f", c_double_p), ("ftmp", c_double_p), ("force", c_double_p),
-                ("mask", C.POINTER(C.c_ubyte)), ("nthreads", C.c_int), ("wall_u", (C.c_double * 3) * 4)]
+                ("mask", C.POINTER(C.c_ubyte)), ("nthreads", C.c_int), ("wall_u", (C.c_double * 3) * 4),
+                ("fused", C.c_int)]
 
 
 class Params(C.Structure):
@@ -85,6 +86,7 @@ def load():
         "orc_lattice_set_force_uniform": (None, [LP, c_double_p]),
         "orc_lattice_set_force_box": (None, [LP, C.POINTER(C.c_int), c_double_p]),
         "orc_collide_stream": (None, [LP]),
+        "orc_collide_stream_fused": (None, [LP]),
         "orc_lattice_set_threads": (None, [LP, C.c_int]),
         "orc_lattice_set_wall_velocity": (None, [LP, C.c_int, c_double_p]),
         "orc_node_rho_u": (None, [LP, C.c_long, c_double_p, c_double_p]),

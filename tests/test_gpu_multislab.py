@@ -24,6 +24,11 @@ PLTS = [((47.0, 12.0, 21.0), (20, 40, 10)), ((120.0, 20.0, 13.0), (0, 0, 0)), ((
 STEPS, K_P, K_M = 250, 2, 4
 FORCE = (3e-4, 0.0, 0.0)
 
+
+# a cell that is pushed into the pipe wall next to the slab face at x = 72 (both ranks hold a copy): every holder must drop it
+# at the next envelope synchronisation (ADVICE round 1: slab runs never deleted such cells); cell 0 stays in the lumen
+WALL_CELLS = [((30.0, 16.5, 16.5), (90, 0, 0)), ((69.0, 16.5, 25.0), (90, 0, 0))]
+
 REPULSION = dict(k=2e-6, cutoff_um=0.7, k_b=3e-6, b_cutoff_um=1.0)   # examples/pipeflow/config.xml:36-38 magnitudes
 
 
@@ -165,6 +170,99 @@ def test_slabs_match_single_domain(tmp_path, gpu, world, rep, padded):
     assert travelled > 5.0, travelled
 
 
+def _oracle_run(orc, nxg, steps, cells=CELLS, plts=PLTS, force=FORCE, k_p=K_P, k_m=K_M, push=None, delete_at_updates=False):
+    """the reference's answer for ANY rank count is the one global block: the oracle on the whole pipe (orc_sim_iterate,
+    core/hemoCell.cpp:299-376).  delete_at_updates: the reference run with verbose.cellsDeletedInfo
+    (core/hemoCell.cpp:360-363: deleteIncompleteCells at the end of every velocity-update iteration), which is what the
+    slab runs do.  -> (populations [n][19], positions, alive flags, lattice, sim)"""
+    import ctypes as C
+
+    from hemocell_amd import host
+    from oracle import oracle as O
+    Po = O.make_params(orc)
+    mask, _ = host.pipe_mask(nxg, NY, NZ)
+    Lo = O.OracleLattice(orc, nxg, NY, NZ, (1, 0, 0), 1.0 / Po.tau)
+    Lo.set_mask(mask); Lo.init_equilibrium(); Lo.set_threads(8)
+    So = orc.orc_sim_create(Lo.ptr, C.byref(Po))
+    for mk in (O.make_rbc, O.make_plt):
+        T = mk(orc, Po); T.contents.timescale = k_m
+        orc.orc_sim_add_type(So, T)
+    So.contents.particle_velocity_timescale = k_p
+    for t, group in ((0, cells), (1, plts)):
+        for c, a in group:
+            a_ref = np.array(a, dtype=np.float64) * (3.14159265358979323846 / 180.0) * -1.0
+            assert orc.orc_sim_add_cell(So, t, O.dptr(np.array(c, dtype=np.float64)), O.dptr(a_ref), 0.0) == 1
+    Lo.set_force_uniform(force)
+    for d in range(3):
+        So.contents.body_force[d] = force[d]
+    orc.orc_sim_mechanics(So, 1)
+    for it in range(steps):
+        orc.orc_sim_iterate(So)
+        if delete_at_updates and it % k_p == 0:
+            orc.orc_sim_delete_incomplete_cells(So)
+        if it == 0 and push is not None:           # _run(): after iteration 0 has interpolated, that cell gets a held velocity
+            vel = np.zeros((So.contents.np, 3)); orc.orc_sim_get(So, 1, O.dptr(vel))
+            nv = 642
+            vel[push[0] * nv:(push[0] + 1) * nv] = np.array(push[1])
+            orc.orc_sim_set(So, 1, O.dptr(vel))
+    pos = np.zeros((So.contents.np, 3)); orc.orc_sim_get(So, 0, O.dptr(pos))
+    alive = np.zeros(So.contents.np, dtype=np.uint8); orc.orc_sim_get_alive(So, alive.ctypes.data)
+    return Lo.f.copy(), pos, alive.astype(bool), mask
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slabs_match_the_oracle(tmp_path, gpu, orc, world):
+    """row a12 against the ORACLE, not against the HIP single domain: the reference's result does not depend on the number
+    of ranks (scripts/ci/pipeflow_sanity.sh:25-33), so N slabs must give what the oracle gives on the one global block --
+    RBC + PLT, cadence (4, 2), a cell across the periodic seam and cells across the interior faces (x = 72; x = 48 and 96),
+    envelope copies created and dropped on the way (core/hemoCellFields.cpp:377-499, periodic shift
+    core/hemoCellParticleDataTransfer.cpp:33-65, merge core/hemoCellParticleField.cpp:173-235).  Same tolerance as the single
+    domain meets in test_iterate_trajectories_vs_oracle: 1e-9 on positions (north_star asks for 1e-6 relative)."""
+    steps = 120
+    res = _spawn(world, tmp_path, dict(), steps=steps, salt=20 + world)
+    f_o, p_o, alive, mask = _oracle_run(orc, NXG, steps)
+    assert alive.all()
+    f_s = np.concatenate([r["f"].reshape(NXG // world, NY * NZ, 19) for r in res], axis=0)
+    fluid = (mask.reshape(NXG, NY * NZ) == 0)
+    f_o = f_o.reshape(NXG, NY * NZ, 19)
+    err_f = np.abs(f_s - f_o)[fluid].max()
+    assert err_f <= 1e-6 * np.abs(f_o[fluid]).max()
+    assert err_f <= 1e-11, err_f
+    nrbc = len(CELLS) * 642
+    worst, moved = 0.0, 0.0
+    for key, p_ref in ((("cid", "vid", "pos"), p_o[:nrbc].reshape(len(CELLS), -1, 3)), (("pcid", "pvid", "ppos"), p_o[nrbc:].reshape(len(PLTS), -1, 3))):
+        seen = np.zeros(p_ref.shape[:2], dtype=int)
+        for r in res:
+            d = r[key[2]] - p_ref[r[key[0]], r[key[1]]]
+            d[:, 0] = (d[:, 0] + NXG / 2) % NXG - NXG / 2       # the oracle keeps global unwrapped positions too; a slab may hold the image
+            worst = max(worst, np.abs(d).max() if len(d) else 0.0)
+            np.add.at(seen, (r[key[0]], r[key[1]]), 1)
+        assert (seen == 1).all()
+    assert worst <= 1e-9, worst
+    assert sum(int(r["held"]) for r in res) > len(CELLS) + len(PLTS)
+    assert sum(r["stats"]["cells_new"] + r["stats"]["cells_dropped"] for r in res) > 0      # copies changed hands
+    assert np.abs(p_o[:, 0] - _initial_x()).max() > 1.5                                       # and the cells did travel
+
+
+def test_wall_deletion_on_slabs_matches_the_oracle(tmp_path, gpu, orc):
+    """a cell pushed into the pipe wall next to the slab face (both ranks hold a copy), reference deletion semantics
+    (single particles leave, core/hemoCellParticleField.cpp:566-588; the remnant goes at the next velocity update,
+    core/hemoCell.cpp:360-363): the two slabs against the oracle on the global block"""
+    kw = dict(cells=WALL_CELLS, plts=[], force=(1e-5, 0.0, 0.0), del_mode="particle", k_p=60)
+    push = (1, (0.0, 0.0, 0.1))
+    steps = 100
+    res = _spawn(2, tmp_path, dict(kw, push=push), steps=steps, salt=31)
+    f_o, p_o, alive, mask = _oracle_run(orc, NXG, steps, cells=WALL_CELLS, plts=[], force=kw["force"], k_p=60, push=push, delete_at_updates=True)
+    assert len(p_o) == 642                                              # the oracle lost the wall cell as well
+    got = np.concatenate([r["pos"] for r in res]); cid = np.concatenate([r["cid"] for r in res]); vid = np.concatenate([r["vid"] for r in res])
+    assert (cid == 0).all() and sorted(vid.tolist()) == list(range(642))
+    assert np.abs(got - p_o[vid]).max() <= 1e-9
+    f_s = np.concatenate([r["f"].reshape(NXG // 2, NY * NZ, 19) for r in res], axis=0)
+    fluid = (mask.reshape(NXG, NY * NZ) == 0)
+    err_f = np.abs(f_s - f_o.reshape(NXG, NY * NZ, 19))[fluid].max()
+    assert err_f <= 1e-11, err_f
+
+
 # sub-domain forces (cases/kolmogorovFlow/kolmogorovFlow.cpp:136-140): one box across the slab face at x = 72, one across the seam
 # (two boxes, since a box does not wrap), one inside a slab that overrides part of the first
 REGIONS = [((40, 100, 0, NY - 1, 0, NZ - 1), (1e-4, 0.0, 2e-5)), ((130, NXG - 1, 0, NY - 1, 0, NZ // 2), (-2e-4, 1e-5, 0.0)),
@@ -190,9 +288,6 @@ def test_slabs_with_subdomain_forces_match_single_domain(tmp_path, gpu):
         assert np.abs(d).max() <= 1e-10
 
 
-# a cell that is pushed into the pipe wall next to the slab face at x = 72 (both ranks hold a copy): every holder must drop it
-# at the next envelope synchronisation (ADVICE round 1: slab runs never deleted such cells); cell 0 stays in the lumen
-WALL_CELLS = [((30.0, 16.5, 16.5), (90, 0, 0)), ((69.0, 16.5, 25.0), (90, 0, 0))]
 
 
 @pytest.mark.parametrize("mode", ["cell", "particle"])

@@ -33,6 +33,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--copy-reps", type=int, default=40, help="repetitions of the 1 GiB copy that measures this GPU's copy bandwidth")
+    ap.add_argument("--config", choices=["headline", "c3"], default="headline",
+                    help="headline: BASELINE's metric workload, weak scaling (N x 256^3).  c3: BASELINE config 3, STRONG scaling -- the 512x256x256 pipe "
+                         "at 10 % Hct with RBC and 0.07 PLT per RBC, cut into N slabs of 512/N planes (64 planes each on 8 GPUs)")
     ap.add_argument("--nx", type=int, default=256, help="slab thickness per GPU")
     ap.add_argument("--ny", type=int, default=256)
     ap.add_argument("--nz", type=int, default=256)
@@ -47,6 +50,10 @@ def parse():
     ap.add_argument("--plane-padding", choices=["auto", "on", "off"], default="auto", help="A/B: padded x-plane stride (auto: planes that are a multiple of 1 MiB)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="A/B: one stream only (by default advance, mechanics and the next spread run beside the collide between velocity updates)")
+    ap.add_argument("--spread-after-collide", action="store_true",
+                    help="A/B: only advance and mechanics run beside the collide, the next spread follows it on the main stream")
+    ap.add_argument("--reproducible-spread", action="store_true",
+                    help="parity mode: the gather-form spread (sums in cell-id order, bit-identical from run to run) instead of the fp64 atomics")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--transport", choices=["rccl", "tcp"], default=None,
                     help="data plane of an N > 1 run: rccl (default), or tcp = the same messages through the library's host mesh, "
@@ -241,6 +248,10 @@ def main():
         return launch_ranks(args)
     if world != args.gpus:
         sys.exit("bench.py --gpus %d was started in a world of %d ranks" % (args.gpus, world))
+    if args.config == "c3":
+        if 512 % world:
+            sys.exit("bench.py --config c3: 512 planes do not divide into %d slabs" % world)
+        args.nx, args.ny, args.nz, args.plt_ratio = 512 // world, 256, 256, 0.07
     # stdout carries exactly one line, the JSON result: RCCL prints its version banner to stdout, so everything else
     # that writes to file descriptor 1 is sent to stderr
     sys.stdout.flush()
@@ -259,6 +270,10 @@ def main():
         host.init(0)
     if args.no_overlap:
         host.check(lib.hc_set_overlap(0))
+    if args.spread_after_collide:
+        host.check(lib.hc_set_overlap(2))
+    if args.reproducible_spread:
+        host.check(lib.hc_set_reproducible_spread(1))
     host.check(lib.hc_debug_force_plane_padding({"auto": 0, "on": 1, "off": -1}[args.plane_padding]))
 
     P, runner, R, n_cells = make_workload(args, args.nx, args.ny, args.nz, rank, world)
@@ -299,6 +314,13 @@ def main():
         nverts = nverts_local; fluid_nodes, active_nodes = int(counts[1]), int(counts[2])
         host_ms_per_step = header_wait_ms = None
 
+    # state of the run after the timed region, reduced over the slabs: the same numbers for any number of ranks (strong scaling)
+    # or per unit of pipe (weak scaling); tests compare the N-slab figures with the 1-slab ones
+    u_stats = runner.fluid_stats(0); rho_stats = runner.fluid_stats(2); v_stats = runner.vertex_stats(1)
+    diagnostics = {"fluid_speed_max": u_stats[1], "fluid_speed_mean": u_stats[2], "fluid_nodes": u_stats[3],
+                   "mass": rho_stats[2] * rho_stats[3], "density_min": rho_stats[0], "density_max": rho_stats[1],
+                   "vertex_speed_max": v_stats[1], "vertex_speed_mean": v_stats[2], "owned_vertices": v_stats[3]}
+
     ms, n = C.c_double(), C.c_long()
     host.check(lib.hc_profile_read(b"collide_stream", C.byref(ms), C.byref(n)))
     prof = {}
@@ -330,7 +352,11 @@ def main():
         launch_nodes = step_nodes / launches_per_step            # algorithmic share of one launch, on average
         avg_ms = ms.value / max(n.value, 1)                       # average duration of ONE launch (what rocprofv3 --stats averages too)
         step_ms = ms.value / args.steps                           # the collide launches of one iteration together
-        achieved = launch_nodes * bytes_per_node / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # units one launch processes = the nodes it VISITS (the kernel creates no threads for inert solid: 83.6 % of the 256^3 box);
+        # the same figure over every node of the box is kept as `frac_whole_box_convention` (what rounds 1-2 printed as `frac`)
+        visited_per_launch = (active_nodes / world) / launches_per_step
+        achieved = visited_per_launch * bytes_per_node / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        achieved_box = launch_nodes * bytes_per_node / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM bytes per launch of that kernel from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
         # passes, FETCH doubled per the gfx950 note): measured offline on exactly this workload AND this build of the kernel
         # (hc_build_tag = hash of csrc/lattice.hip) and committed under profiles/; otherwise null
@@ -344,9 +370,9 @@ def main():
                     traffic_src = "profiles/%s (rocprofv3 --pmc, %.1f B/node, kernel build %s)" % (tf, traffic_per_node, tag)
                     break
         out = {
-            "metric": "MLUPS + cell-vertex updates/s, 256^3 pipeflow 10% Hct",
+            "metric": "MLUPS + cell-vertex updates/s, 256^3 pipeflow 10% Hct" if args.config == "headline" else "MLUPS + cell-vertex updates/s, 512x256x256 pipeflow 10% Hct RBC+PLT (BASELINE config 3)",
             "value": mlups, "unit": "MLUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.config == "headline" else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "vertex_updates_per_s": nverts * args.steps / elapsed,
             # the same rate counted over the fluid nodes only, and what share of the box the kernel touches
@@ -354,32 +380,38 @@ def main():
             "fluid_node_fraction": fluid_nodes / nodes, "active_node_fraction": active_nodes / nodes,
             "config": {"workload": "examples/pipeflow synthetic: pipe %dx%dx%d (x periodic, analytic cylinder R=%.0f, bounce-back), "
                                    "%d cells (rbcHighOrderModel, 642 vertices each, target Hct %.2f; pltSimpleModel platelets per RBC: %g), tau=%.2f, "
-                                   "stepParticleEvery=5, stepMaterialEvery=20, wall deletions checked every step%s"
-                                   % (nxg, args.ny, args.nz, R, n_cells, args.hematocrit, args.plt_ratio, P.tau, (", fully periodic box without walls (cases/performance_testing)" if args.periodic_box else ", fluid only") if args.fluid_only else ""),
+                                   "stepParticleEvery=5, stepMaterialEvery=20, wall deletions checked every step%s%s"
+                                   % (nxg, args.ny, args.nz, R, n_cells, args.hematocrit, args.plt_ratio, P.tau, (", fully periodic box without walls (cases/performance_testing)" if args.periodic_box else ", fluid only") if args.fluid_only else "",
+                                      ", reproducible (gather-form) spread" if args.reproducible_spread else ""),
                        "lattice": [nxg, args.ny, args.nz], "cells": n_cells, "vertices": nverts,
                        "parallelism": "x-slabs x%d, native slab schedule (csrc/slab.hip), %s point-to-point" % (world, {0: "no", 1: "RCCL", 2: "TCP-staged"}[slab.comm_info()[2]]) if world > 1 else "1 GPU"},
-            # `achieved` / `frac` follow SURVEY.md section 8(d): ALGORITHMIC bytes (353 B x every node of the box, solid ones
-            # included) over the kernel's time.  The kernel skips inert solid nodes, so the bytes that really move are fewer:
-            # `traffic` (PMC) and `frac_real_traffic` = traffic / time / peak say what the HBM actually delivered.
+            # `achieved` / `frac`: SURVEY.md section 8(d)'s ALGORITHMIC bytes per node (353 B) x the nodes one launch processes (the
+            # visited ones) over the kernel's average launch time.  `traffic` (PMC) and `frac_real_traffic` = traffic / time / peak say
+            # what the HBM actually delivered; `frac_whole_box_convention` counts the inert solid nodes as if they moved too.
             "roofline": {"bound": "hbm", "kernel": "collide_stream_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac_whole_box_convention": achieved_box / 8000.0,
                          # `traffic` is HBM bytes per ITERATION (all collide launches of a step, PMC sum); real rate = traffic / their time
                          "frac_real_traffic": (traffic / (step_ms * 1e-3) / 8.0e12) if (traffic and step_ms > 0) else None,
                          "real_traffic_GBps": (traffic / (step_ms * 1e-3) / 1e9) if (traffic and step_ms > 0) else None,
                          # without a PMC figure for this workload: the bytes of the nodes the kernel visits (an upper bound of what moves)
                          "frac_active_nodes": (active_nodes / world) * bytes_per_node / (step_ms * 1e-3) / 8.0e12 if step_ms > 0 else None,
-                         "algorithmic_bytes_per_launch": launch_nodes * bytes_per_node,
-                         "bytes_per_node": bytes_per_node, "nodes_per_launch": launch_nodes, "avg_launch_ms": avg_ms,
+                         "algorithmic_bytes_per_launch": visited_per_launch * bytes_per_node,
+                         "bytes_per_node": bytes_per_node, "nodes_per_launch": visited_per_launch, "box_nodes_per_launch": launch_nodes, "avg_launch_ms": avg_ms,
                          "launches": n.value, "launches_per_step": launches_per_step, "collide_ms_per_step": step_ms, "kernel_build": tag,
                          "peak_source": "MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)",
                          "copy_GBps_this_gpu": cbw.value},
             "kernel_ms": prof,
+            "diagnostics": diagnostics,
             # the same kernel with the GPU to itself (10 launches right after the timed region)
-            "roofline_alone": ({"avg_launch_ms": alone_ms, "launches": 10, "frac": step_nodes * bytes_per_node / (alone_ms * 1e-3) / 8.0e12,
+            "roofline_alone": ({"avg_launch_ms": alone_ms, "launches": 10, "frac": active_nodes * bytes_per_node / (alone_ms * 1e-3) / 8.0e12,
+                                "frac_whole_box_convention": step_nodes * bytes_per_node / (alone_ms * 1e-3) / 8.0e12,
                                 "frac_real_traffic": (traffic / (alone_ms * 1e-3) / 8.0e12) if traffic else None} if alone_ms else None),
             # whole job against the HBM roofline of the whole step: MLUPS x algorithmic bytes per node update over the
             # aggregate 8 TB/s of the GPUs used (north_star: >= 0.60 on the 512^3 pipe at 1 GPU)
             "whole_step_hbm_frac": mlups * 1e6 * bytes_per_node / (8.0e12 * world),
+            # the same over the nodes the kernel visits (inert solid does not count as moved)
+            "whole_step_hbm_frac_active_nodes": active_nodes * args.steps / elapsed * bytes_per_node / (8.0e12 * world),
         }
         if world > 1:
             # host side of the native slab schedule (csrc/slab.hip), mean over the ranks: time spent enqueueing a step, and how long

@@ -56,6 +56,8 @@ SIGNATURES = {
     "hc_slab_stats": (C.c_int, [VP, c_double_p, C.c_int]),
     "hcl_slab_refresh_halos": (C.c_int, [VP, C.c_int]),
     "hcp_slab_sync_placement": (C.c_int, [VP, c_long_p]),
+    "hcp_set_envelope": (C.c_int, [VP, C.c_double, c_double_p]),
+    "hcp_envelope": (C.c_int, [VP, c_double_p, c_long_p]),
     "hcp_set_deletion_mode": (C.c_int, [VP, C.c_int]),
     "hcp_delete_incomplete_cells": (C.c_int, [VP, c_long_p]),
     "hcp_deletion_counts": (C.c_int, [VP, c_long_p, c_long_p, c_long_p, c_long_p]),
@@ -67,6 +69,7 @@ SIGNATURES = {
     "hc_measure_copy_bandwidth": (C.c_int, [C.c_size_t, C.c_int, c_double_p]),
     "hcl_node_counts": (C.c_int, [VP, c_long_p]),
     "hc_debug_ibm_per_vertex": (C.c_int, [C.c_int]),
+    "hc_set_reproducible_spread": (C.c_int, [C.c_int]),
     "hc_debug_force_plane_padding": (C.c_int, [C.c_int]),
     "hcl_create": (C.c_int, [C.POINTER(VP), C.c_int, C.c_int, C.c_int, c_int_p, C.c_double, C.c_int, C.c_int, C.c_int]),
     "hcl_destroy": (C.c_int, [VP]),
@@ -88,6 +91,7 @@ SIGNATURES = {
     "hcl_halo_pack": (C.c_int, [VP, C.c_int, C.c_int, VP]),
     "hcl_halo_unpack": (C.c_int, [VP, C.c_int, C.c_int, VP]),
     "hcl_halo_pack_next": (C.c_int, [VP, C.c_int, C.c_int, VP]),
+    "hcl_face_velocity_pack": (C.c_int, [VP, C.c_int, VP]),
     "hcl_dims": (C.c_int, [VP, c_int_p]),
     "hcl_mlups_bytes_per_node": (C.c_double, [VP]),
     "hc_params_base": (C.c_int, [C.POINTER(Params)] + [C.c_double] * 5),

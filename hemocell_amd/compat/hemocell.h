@@ -533,7 +533,12 @@ class HemoCell {
   }
 
   void latticeEquilibrium(T rho, hemo::Array<T, 3> vel) { lattice->eq_rho = rho; for (int d = 0; d < 3; d++) lattice->eq_u[d] = vel[d]; lattice->dirty_layout = true; }
-  void initializeCellfield() { cellfields = new HemoCellFields(*this); }
+  void initializeCellfield() {
+    cellfields = new HemoCellFields(*this);
+    int env = 25;   // core/hemoCell.cpp:139 reads it here; core/hemoCellFields.cpp:43 prints it.  Used by loadParticles() on slab runs
+    try { env = (*cfg)["domain"]["particleEnvelope"].read<int>(); } catch (const std::invalid_argument &) {}
+    hlog << "(Hemocell) (HemoCellFields) (Init) particle envelope: " << env << " [lu]" << std::endl;
+  }
   // core/hemoCell.cpp:438-474: the lattice from the block management alone, GuoExternalForceBGKdynamics(1/tau) as the bulk
   // dynamics.  <domain><mABx/y/z> (an explicit block layout) does not apply: every rank holds one x-slab.
   void initializeLattice(plb::MultiBlockManagement3D const &management) {
@@ -817,6 +822,14 @@ inline void HemoCell::loadParticles() {
   cellfields->number_of_cells = total;
   vector<int> placed_per_type;
   const T posRatio = 1e-6 / Parameters::dx;
+  if (global.world > 1 && cellfields->size() > 0) {
+    // <domain><particleEnvelope> (core/hemoCell.cpp:139): how far from a slab face cells are replicated on the neighbour
+    double env = 25.0, share = 0.0;
+    try { env = (double)(*cfg)["domain"]["particleEnvelope"].read<int>(); } catch (const std::invalid_argument &) {}
+    hc_check(hcp_set_envelope(c, env, &share), "hcp_set_envelope");
+    // not in the logfile: the reference's CI compares the logfiles of runs with different rank counts (scripts/ci/pipeflow_sanity.sh:23-33)
+    if (global.rank == 0) std::cout << "(HemoCell) (CellFields) whole cells are replicated within " << share << " [lu] of a slab face" << std::endl;
+  }
   for (unsigned int j = 0; j < cellfields->size(); j++) {
     HemoCellField *field = (*cellfields)[j];
     std::ifstream f((field->name + ".pos").c_str());
@@ -876,12 +889,14 @@ inline void HemoCell::saveCheckPoint() {
     rename((dir + "/checkpoint.xml").c_str(), (dir + "/checkpoint.xml.old").c_str());
   }
   hc_comm_barrier();
-  rename(checkpoint_file(dir).c_str(), (checkpoint_file(dir) + ".old").c_str());   // :283-290 keeps the previous one
   hc_lattice *d = lattice->device(); hc_cells *c = cellfields->device();
   const size_t n = (size_t)lattice->nxl * lattice->ny * lattice->nz;
   vector<double> f(n * HC_Q);
   hc_check(hcl_download_populations(d, f.data()), "hcl_download_populations");
-  std::ofstream o(checkpoint_file(dir).c_str(), std::ios::binary);
+  // written next to its final name and renamed into place when complete: a run that dies while saving leaves the previous
+  // checkpoint (core/hemoCellFields.cpp:283-290 keeps it as .old) and never a truncated one under the name that is loaded
+  const string final_name = checkpoint_file(dir), tmp_name = final_name + ".tmp";
+  std::ofstream o(tmp_name.c_str(), std::ios::binary);
   const long hdr[8] = {0x48434b51, (long)iter, lattice->nx, lattice->ny, lattice->nz, (long)cellfields->size(), lattice->x0, lattice->nxl};
   o.write((const char *)hdr, sizeof(hdr));
   o.write((const char *)f.data(), (std::streamsize)(f.size() * sizeof(double)));
@@ -893,6 +908,10 @@ inline void HemoCell::saveCheckPoint() {
   if (nrec) hc_check(hcp_download_records(c, rec.data(), nrec), "hcp_download_records");
   o.write((const char *)&nrec, sizeof(long));
   o.write((const char *)rec.data(), (std::streamsize)(rec.size() * sizeof(rec[0])));
+  o.close();
+  if (!o) { hlog << "(HemoCell) (saveCheckPoint) could not write " << tmp_name << endl; std::exit(1); }
+  rename(final_name.c_str(), (final_name + ".old").c_str());
+  rename(tmp_name.c_str(), final_name.c_str());
   if (global.rank == 0) {
     std::ofstream x((dir + "/checkpoint.xml").c_str());
     x << "<?xml version=\"1.0\" ?>\n<Checkpoint>\n<General><Iteration>" << iter << "</Iteration><OutDirectory>" << outDir << "/</OutDirectory></General>\n";
@@ -914,21 +933,36 @@ inline void HemoCell::loadCheckPoint() {
   std::ifstream in(checkpoint_file(dir).c_str(), std::ios::binary);
   if (!in.is_open()) { hlog << "(HemoCell) (loadCheckPoint) " << checkpoint_file(dir) << " not found" << endl; std::exit(1); }
   hc_lattice *d = lattice->device(); hc_cells *c = cellfields->device();
-  long hdr[8]; in.read((char *)hdr, sizeof(hdr));
+  in.seekg(0, std::ios::end); const long file_bytes = (long)in.tellg(); in.seekg(0, std::ios::beg);
+  auto truncated = [&]() { hlog << "(HemoCell) (loadCheckPoint) " << checkpoint_file(dir) << " is truncated or damaged" << endl; std::exit(1); };
+  long hdr[8] = {0}; in.read((char *)hdr, sizeof(hdr));
+  if (!in.good()) truncated();
   if (hdr[0] != 0x48434b51 || hdr[2] != lattice->nx || hdr[3] != lattice->ny || hdr[4] != lattice->nz || hdr[5] != (long)cellfields->size() || hdr[6] != lattice->x0 || hdr[7] != lattice->nxl) {
     hlog << "(HemoCell) (loadCheckPoint) checkpoint does not match this case (lattice size / cell types / number of ranks)" << endl; std::exit(1);
   }
   const size_t n = (size_t)lattice->nxl * lattice->ny * lattice->nz;
   vector<double> f(n * HC_Q);
   in.read((char *)f.data(), (std::streamsize)(f.size() * sizeof(double)));
-  hc_check(hcl_upload_populations(d, f.data()), "hcl_upload_populations");
-  long nrec = 0; in.read((char *)&nrec, sizeof(long));
+  if (!in.good()) truncated();
+  long nrec = -1; in.read((char *)&nrec, sizeof(long));
+  const long rec_bytes = (long)sizeof(HemoCellParticle::serializeValues_t);
+  if (!in.good() || nrec < 0 || nrec > (file_bytes - (long)in.tellg()) / rec_bytes) truncated();
   vector<HemoCellParticle::serializeValues_t> rec((size_t)nrec);
   in.read((char *)rec.data(), (std::streamsize)(rec.size() * sizeof(rec[0])));
+  if (nrec && !in.good()) truncated();
+  if (global.world > 1) {   // every rank writes its own file: all of them must hold the same iteration
+    double lo = (double)hdr[1], hi = (double)hdr[1];
+    hc_check(hc_comm_allreduce(&lo, 1, 1), "hc_comm_allreduce"); hc_check(hc_comm_allreduce(&hi, 1, 2), "hc_comm_allreduce");
+    if (lo != hi) { hlog << "(HemoCell) (loadCheckPoint) the ranks hold checkpoints of different iterations (" << (long)lo << " ... " << (long)hi << ")" << endl; std::exit(1); }
+  }
+  hc_check(hcl_upload_populations(d, f.data()), "hcl_upload_populations");
   // a repulsion the driver enabled has to exist before the records arrive, or their force_repulsion would be dropped
   if (boundaryRepulsionEnabled && !boundaryRepulsionPushed) { hc_check(hcp_set_boundary_repulsion(c, boundaryRepulsionConstant_, boundaryRepulsionCutoff_, (int)boundaryRepulsionTimescale), "hcp_set_boundary_repulsion"); boundaryRepulsionPushed = true; }
   if (repulsionEnabled && !repulsionPushed) { hc_check(hcp_set_repulsion(c, repulsionConstant_, repulsionCutoff_, (int)repulsionTimescale), "hcp_set_repulsion"); repulsionPushed = true; }
   hc_check(hcp_upload_records(c, rec.data(), nrec), "hcp_upload_records");
+  // core/hemoCellFields.cpp:272-274: load, syncEnvelopes, deleteIncompleteCells -- a checkpoint written while a cell had lost
+  // particles at a wall (removeParticles(1)) holds that cell incomplete
+  hc_check(hcp_delete_incomplete_cells(c, nullptr), "hcp_delete_incomplete_cells");
   long nct = 0; hcp_counts(c, nullptr, &nct, nullptr);
   cellfields->number_of_cells = (int)nct;
   iter = (unsigned int)hdr[1];

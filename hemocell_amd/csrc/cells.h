@@ -66,15 +66,29 @@ struct hc_cells {
   unsigned int *d_keys[2] = {nullptr, nullptr}; int *d_vals[2] = {nullptr, nullptr}; void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0; long sort_cap = 0;
   // staged slot lists (envelope exchange, interpolate_cells, remove): pinned host block -> device block, stream ordered;
   // the event guards the pinned block against being rewritten while its copy is still in flight
-  int *d_iscratch[2] = {nullptr, nullptr}, *h_iscratch[2] = {nullptr, nullptr}; hipEvent_t iscratch_ev[2] = {nullptr, nullptr};
+  int *d_iscratch[3] = {nullptr, nullptr, nullptr}, *h_iscratch[3] = {nullptr, nullptr, nullptr}; hipEvent_t iscratch_ev[3] = {nullptr, nullptr, nullptr};
   // asynchronous cell extents (hcp_cell_extents_begin / _end): device block, pinned host block and event per type
   double *d_ext[8] = {nullptr}, *h_ext[8] = {nullptr}; long ext_cap[8] = {0}, ext_n[8] = {0}; hipEvent_t ext_done[8] = {nullptr}; bool ext_pending[8] = {false};
   // staging of hcp_add_vertex_force (called every iteration by the stretch drivers): pinned host block + device block
   // [n indices | 3n force components], grown on demand; the event guards the pinned block against reuse in flight
   char *h_vf = nullptr, *d_vf = nullptr; size_t vf_cap = 0; hipEvent_t vf_done = nullptr;
-  size_t iscratch_cap[2] = {0, 0};
+  size_t iscratch_cap[3] = {0, 0, 0};
+  // reproducible spread (hc_set_reproducible_spread): (node, entry) pairs of every (particle, stencil node), both sort buffers,
+  // and the three force components of every entry
+  unsigned int *det_keys[2] = {nullptr, nullptr}; int *det_vals[2] = {nullptr, nullptr}; double *det_val[3] = {nullptr, nullptr, nullptr};
+  void *det_tmp = nullptr; size_t det_tmp_bytes = 0; long det_cap = 0;
   double *d_stat = nullptr, *h_stat = nullptr;   // [STAT_BLOCKS][4] partials of the statistics reductions, device and pinned host
   double *d_info = nullptr, *h_info = nullptr; size_t info_cap = 0;   // scratch of the information calls (hcp_cell_info, hcp_mechanics_components, statistics)
+  // slab runs: ids of cells this rank compacted away on its own (a host query between two envelope synchronisations:
+  // counts, output, deleteIncompleteCells) -- the next synchronisation tells the other holders, or their copy would come
+  // back as a fresh complete cell
+  std::vector<long> slab_gone[8];
+  // slab runs: a cell that reaches within e_share lattice units of a face is replicated on the neighbour (the cell-granular
+  // form of the reference's particle envelope, core/hemoCell.cpp:139; hcp_set_envelope).  env_viol counts the copies that
+  // arrived too late -- a particle already sat on the receiving slab's side when its cell first got there (mapped pinned
+  // memory, written by unpack_cells_kernel)
+  double e_share = 4.0;
+  int *h_env_viol = nullptr, *d_env_viol = nullptr;
   std::vector<long> slab_rejected;   // (type, cell id) pairs hcp_add_cell rejected at a wall on this slab, until hcp_slab_sync_placement
   long n_deleted = 0;              // cells removed entirely
   long n_particles_deleted = 0;    // single particles removed (reference mode), including those of cells removed later
@@ -82,7 +96,7 @@ struct hc_cells {
 
 namespace hcc {
 
-constexpr double E_SHARE = 4.0;   // slab runs: a cell within this many lattice units of a face is replicated on the neighbour
+constexpr double E_SHARE_DEFAULT = 4.0, E_SHARE_MIN = 2.0;   // slab runs, hc_cells::e_share: default, and the least that still covers the IBM stencil
 
 // ----------------------------------------------------------------------------
 // lattice view for the IBM kernels
@@ -95,6 +109,8 @@ struct LatView {
   int nx_global;
   uint8_t *dirty; uint8_t epoch;   // dirty map of the force buffer spread adds to (see common.h)
   const uint8_t *wallbrick; int nby, nbz;   // wall proximity per 8^3 brick (see common.h)
+  const double *halo_u[2];                  // slab runs: owner-evaluated node velocities of the first halo planes (null: gather them here)
+  int ny_nz;                                // nodes of one x-plane (stride of the three components of halo_u)
 };
 
 inline LatView make_view(const hc_lattice *L) {
@@ -104,6 +120,7 @@ inline LatView make_view(const hc_lattice *L) {
   v.per_y = L->periodic[1]; v.per_z = L->periodic[2]; v.nx_global = L->nx_global;
   v.dirty = L->fdirty[L->fcur]; v.epoch = L->fepoch[L->fcur];
   v.wallbrick = L->wallbrick; v.nby = L->nby; v.nbz = L->nbz;
+  v.halo_u[0] = L->halo_u_valid ? L->halo_u[0] : nullptr; v.halo_u[1] = L->halo_u_valid ? L->halo_u[1] : nullptr; v.ny_nz = (int)L->plane;
   return v;
 }
 

@@ -322,7 +322,43 @@ int hcp_create(hc_cells **out, hc_lattice *L, const hc_params *P) {
   HC_HIP(hipMalloc((void **)&C->d_ntag, 4 * sizeof(int)));
   HC_HIP(hipMemset(C->d_ntag, 0, 4 * sizeof(int)));
   HC_HIP(hipEventCreateWithFlags(&C->ntag_ev, hipEventDisableTiming));
+  HC_HIP(hipHostMalloc((void **)&C->h_env_viol, sizeof(int), hipHostMallocMapped));
+  HC_HIP(hipHostGetDevicePointer((void **)&C->d_env_viol, C->h_env_viol, 0));
+  *C->h_env_viol = 0;
   *out = C;
+  return HC_OK;
+}
+
+// The particle envelope of a slab run: <particleEnvelope> of the configuration, in lattice units.  The reference replicates
+// single particles within that distance of a block face on the neighbour (core/hemoCell.cpp:139, core/hemoCellFields.cpp:39-43);
+// here whole cells are replicated, so an envelope E acts as share = E - (diameter of the largest cell type): the distance a cell
+// may still travel towards the face, between two velocity updates, before a complete copy must exist on the other side.  The
+// slab has to keep the two faces' envelopes and a cell apart (nx >= 2 * diameter + 2 * share, the rule make_slab enforces): a
+// request beyond that is CLAMPED to what the slab supports and the share in use is returned; a slab that cannot even hold
+// E_SHARE_MIN is refused.
+int hcp_set_envelope(hc_cells *C, double particle_envelope_lu, double *share_in_use) {
+  HC_REQUIRE(C, "hcp_set_envelope: null pointer");
+  HC_REQUIRE(particle_envelope_lu > 0.0 && particle_envelope_lu < 1e6, "hcp_set_envelope: the envelope must be a positive number of lattice units");
+  HC_REQUIRE(C->ntypes > 0, "hcp_set_envelope: add the cell types first (the envelope is measured against the largest cell)");
+  for (int t = 0; t < C->ntypes; t++) HC_REQUIRE(C->hids[t].empty(), "hcp_set_envelope: set the envelope before the first cell is placed (placement already uses it)");
+  double dmax = 0.0;
+  for (int t = 0; t < C->ntypes; t++) dmax = std::max(dmax, C->types[t]->host.diameter);
+  double share = std::max(particle_envelope_lu - dmax, E_SHARE_MIN);
+  const hc_lattice *L = C->L;
+  if (L->n_slabs > 1) {
+    const double room = 0.5 * ((double)L->nx - 2.0 * dmax);
+    if (room < E_SHARE_MIN) { hc::set_error("hcp_set_envelope: a slab of " + std::to_string(L->nx) + " planes cannot hold two cell diameters (" + std::to_string(2.0 * dmax) + " lu) and a particle envelope"); return HC_ERR_ARG; }
+    share = std::min(share, std::floor(room * 16.0) / 16.0);
+  }
+  C->e_share = share;
+  if (share_in_use) *share_in_use = share;
+  return HC_OK;
+}
+
+int hcp_envelope(const hc_cells *C, double *share_in_use, long *late_copies) {
+  HC_REQUIRE(C, "hcp_envelope: null pointer");
+  if (share_in_use) *share_in_use = C->e_share;
+  if (late_copies) *late_copies = C->h_env_viol ? (long)*C->h_env_viol : 0;
   return HC_OK;
 }
 
@@ -333,8 +369,12 @@ int hcp_destroy(hc_cells *C) {
   if (C->h_ntag) hipHostFree(C->h_ntag);
   if (C->d_ntag) hipFree(C->d_ntag);
   if (C->ntag_ev) hipEventDestroy(C->ntag_ev);
+  if (C->h_env_viol) hipHostFree(C->h_env_viol);
   if (C->d_bflag) hipFree(C->d_bflag);
-  for (int k = 0; k < 2; k++) { if (C->h_iscratch[k]) hipHostFree(C->h_iscratch[k]); if (C->iscratch_ev[k]) hipEventDestroy(C->iscratch_ev[k]); }
+  for (int k = 0; k < 3; k++) { if (C->h_iscratch[k]) hipHostFree(C->h_iscratch[k]); if (C->iscratch_ev[k]) hipEventDestroy(C->iscratch_ev[k]); }
+  for (int k = 0; k < 2; k++) { if (C->det_keys[k]) hipFree(C->det_keys[k]); if (C->det_vals[k]) hipFree(C->det_vals[k]); }
+  for (int k = 0; k < 3; k++) if (C->det_val[k]) hipFree(C->det_val[k]);
+  if (C->det_tmp) hipFree(C->det_tmp);
   for (int t = 0; t < 8; t++) { if (C->h_ext[t]) hipHostFree(C->h_ext[t]); if (C->ext_done[t]) hipEventDestroy(C->ext_done[t]); }   // d_ext is the device view of h_ext
   if (C->d_stat) hipFree(C->d_stat);
   if (C->h_stat) hipHostFree(C->h_stat);
@@ -343,7 +383,7 @@ int hcp_destroy(hc_cells *C) {
   if (C->h_vf) hipHostFree(C->h_vf);
   if (C->d_vf) hipFree(C->d_vf);
   if (C->vf_done) hipEventDestroy(C->vf_done);
-  for (int k = 0; k < 2; k++) if (C->d_iscratch[k]) hipFree(C->d_iscratch[k]);
+  for (int k = 0; k < 3; k++) if (C->d_iscratch[k]) hipFree(C->d_iscratch[k]);
   delete C;
   return HC_OK;
 }
@@ -409,7 +449,7 @@ int hcp_add_cell(hc_cells *C, int type, long cell_id, const double centre_lu[3],
         const double g = std::floor(x + 0.5);
         own = own || (g >= x0 && g < x1);
       }
-      if (own || (hi >= x0 - E_SHARE && lo < x1 + E_SHARE)) { mine = true; cx = centre_lu[0] + shifts[k]; }
+      if (own || (hi >= x0 - C->e_share && lo < x1 + C->e_share)) { mine = true; cx = centre_lu[0] + shifts[k]; }
     }
     if (!mine) { if (placed) *placed = 0; return HC_OK; }
   }
@@ -535,9 +575,9 @@ int hcp_download_records(hc_cells *C, void *records, long n_records) {
   return HC_OK;
 }
 
-// Replaces the whole vertex population by the given records (any order).  Every cell must be complete -- one record
-// per vertexId of its type -- as the reference requires before mechanics (deleteIncompleteCells); cells keep the order
-// of their first record within their type.
+// Replaces the whole vertex population by the given records (any order).  A cell that lacks records of some of its
+// vertexIds arrives incomplete (no mechanics until hcp_delete_incomplete_cells removes it, as in the reference); cells
+// keep the order of their first record within their type.
 int hcp_upload_records(hc_cells *C, const void *records, long n_records) {
   HC_REQUIRE(C && (records || n_records == 0) && n_records >= 0, "hcp_upload_records: bad arguments");
   int rc = settle(C); if (rc != HC_OK) return rc;
@@ -563,10 +603,15 @@ int hcp_upload_records(hc_cells *C, const void *records, long n_records) {
     seen[t][v] = 1;
     for (int d = 0; d < 3; d++) { pos[t][3 * v + d] = r.position[d]; vel[t][3 * v + d] = r.v[d]; frc[t][3 * v + d] = r.force[d]; rep[t][3 * v + d] = r.force_repulsion[d]; }
   }
-  for (int t = 0; t < C->ntypes; t++) for (int s : seen[t]) HC_REQUIRE(s, "hcp_upload_records: incomplete cell (a vertexId is missing)");
+  // A cell with a vertexId missing is what removeParticles(1) leaves behind (core/hemoCellParticleField.cpp:304-321) and what a
+  // checkpoint written between two deleteIncompleteCells holds: it arrives as the incomplete cell it was (tag 2, the missing
+  // particles flagged as removed), exactly the state hcp_download_records serialised; the reference's load path then runs
+  // deleteIncompleteCells (core/hemoCellFields.cpp:272-274), which is the caller's next call.
   for (int t = 0; t < C->ntypes; t++) {
+    const size_t nv = (size_t)C->types[t]->host.nv;
     C->hids[t].swap(ids[t]); C->hpos[t].swap(pos[t]); C->hvel[t].swap(vel[t]); C->hfrc[t].swap(frc[t]);
-    C->htag[t].assign(C->hids[t].size(), 0); C->hdead[t].assign(C->hids[t].size() * (size_t)C->types[t]->host.nv, 0);
+    C->htag[t].assign(C->hids[t].size(), 0); C->hdead[t].assign(C->hids[t].size() * nv, 0);
+    for (size_t v = 0; v < seen[t].size(); v++) if (!seen[t][v]) { C->hdead[t][v] = 1; C->htag[t][v / nv] = 2; }
     if (C->rep_on()) C->hrep[t].swap(rep[t]); else C->hrep[t].clear();   // force_repulsion travels through the staging
   }
   C->host_dirty = true;
@@ -631,7 +676,7 @@ static int compact_gone(hc_cells *C) {
     const bool has_rep = C->hrep[t].size() == 3 * nc * nv;
     size_t w = 0;
     for (size_t c = 0; c < nc; c++) {
-      if (C->htag[t][c] == 1) { C->n_deleted++; continue; }
+      if (C->htag[t][c] == 1) { C->n_deleted++; if (C->L && C->L->n_slabs > 1) C->slab_gone[t].push_back(C->hids[t][c]); continue; }
       if (w != c) {
         std::copy(C->hpos[t].begin() + 3 * c * nv, C->hpos[t].begin() + 3 * (c + 1) * nv, C->hpos[t].begin() + 3 * w * nv);
         std::copy(C->hvel[t].begin() + 3 * c * nv, C->hvel[t].begin() + 3 * (c + 1) * nv, C->hvel[t].begin() + 3 * w * nv);
@@ -757,7 +802,8 @@ int hcp_advance(hc_cells *C, int check_deletions) {
 }
 
 static int g_overlap = 1;   // hc_iterate: run advance + mechanics + the next spread beside the collide on steps without a particle update
-int hc_set_overlap(int on) { g_overlap = on != 0; hcs::set_overlap(on); return HC_OK; }
+static int g_spread_beside = 1;   // ... 2 in hc_set_overlap: advance and mechanics only, the next spread follows the collide on the main stream (A/B)
+int hc_set_overlap(int on) { g_overlap = on != 0; g_spread_beside = on != 2; hcs::set_overlap(on); return HC_OK; }
 
 int hc_iterate(hc_lattice *L, hc_cells *C, long *iter, int n, int particle_timescale, int force_limit, int deletion_check_every) {
   HC_REQUIRE(L && C && iter, "hc_iterate: null pointer");
@@ -795,9 +841,8 @@ int hc_iterate(hc_lattice *L, hc_cells *C, long *iter, int n, int particle_times
     if ((rc = hcp_advance(C, 0)) != HC_OK) return rc;                           // :342
     if ((rc = hcp_mechanics(C, it, 0)) != HC_OK) return rc;                     // :345
     if (overlap) {
-      if ((rc = hcp_spread(C, force_limit)) != HC_OK) return rc;                // :313 of iteration it + 1
+      if (g_spread_beside) { if ((rc = hcp_spread(C, force_limit)) != HC_OK) return rc; spread_done = true; }   // :313 of iteration it + 1
       if ((rc = hc::join()) != HC_OK) return rc;
-      spread_done = true;
     }
     *iter = it + 1;                                                             // :374 (force zeroing is fused into the collide kernel)
     if (!overlap && (it + 1) % deletion_check_every == 0 && s + 1 < n) { if ((rc = poll_deletions(C, true)) != HC_OK) return rc; }   // on the main timeline only

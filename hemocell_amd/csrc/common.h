@@ -129,6 +129,11 @@ struct hc_lattice {
   int nblk, max_active;
   double *scratch;       // download staging
   size_t scratch_doubles;
+  // slab runs: node velocities u = j/rho + F/2 of the two neighbours' face planes, evaluated there by their owner after the
+  // last collide (slab.hip); [side][3][plane].  The interpolation reads them for stencil nodes on the first halo plane
+  // instead of gathering 19 populations there.  Valid from the exchange until the next hcl_step_end.
+  double *halo_u[2] = {nullptr, nullptr};
+  bool halo_u_valid = false;
 };
 
 // slab.hip: HemoCell::iterate / collideAndStream on one x-slab of a multi-GPU run (halo and envelope exchange inside)

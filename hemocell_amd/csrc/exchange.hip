@@ -52,12 +52,18 @@ __global__ __launch_bounds__(256) void pack_cells_kernel(int nv, int rec, const 
 // merge rule of HemoCellParticleField::addParticle (core/hemoCellParticleField.cpp:173-235): a local
 // particle wins over an incoming copy; "local" = its nearest lattice node lies in this slab
 __global__ __launch_bounds__(256) void unpack_cells_kernel(int nv, int rec, const int *slots, const int *is_new, VertArrays a, const double *buf,
-                                                           int x0, int nx) {
+                                                           int x0, int nx, int *late) {
   const long dst = (long)slots[blockIdx.x] * nv, src = (long)blockIdx.x * nv;
   const bool fresh = is_new[blockIdx.x] != 0;
   if (fresh && threadIdx.x == 0) a.tag[slots[blockIdx.x]] = 0;   // a new copy is a complete cell, whatever lived in this slot before
   for (int i = threadIdx.x; i < nv; i += 256) {
-    if (fresh) a.dead[dst + i] = 0;
+    if (fresh) {
+      a.dead[dst + i] = 0;
+      // the envelope check: when a cell first arrives none of its particles may already reach this slab's nodes with its
+      // stencil (x in (x0 - 1, x0 + nx)) -- it would have spread and been interpolated here before the copy existed
+      const double x = buf[(src + i) * rec];
+      if (x > (double)x0 - 1.0 && x < (double)(x0 + nx)) atomicAdd_system(late, 1);
+    }
     bool take = fresh;
     if (!take) {
       const long gx = nearest_node(a.p[0][dst + i]) - x0;
@@ -208,9 +214,12 @@ int hcp_unpack_cells(hc_cells *C, int type, const int *slots, const long *cell_i
   if (C->ncells[type] + n_new > C->capc[type]) {
     // slow path: grow the device regions through the host staging
     rc = sync_to_host(C); if (rc != HC_OK) return rc;
-    const size_t add = (size_t)n_new * C->types[type]->host.nv * 3;
-    C->hpos[type].resize(C->hpos[type].size() + add, 0.0); C->hvel[type].resize(C->hvel[type].size() + add, 0.0); C->hfrc[type].resize(C->hfrc[type].size() + add, 0.0);
-    for (int i = 0; i < n; i++) if (is_new[i]) C->hids[type].push_back(cell_ids[i]);
+    const size_t add = (size_t)C->types[type]->host.nv * 3;
+    for (int i = 0; i < n; i++) {
+      if (!is_new[i]) continue;
+      C->hpos[type].resize(C->hpos[type].size() + add, 0.0); C->hvel[type].resize(C->hvel[type].size() + add, 0.0); C->hfrc[type].resize(C->hfrc[type].size() + add, 0.0);
+      host_append_state(C, type, cell_ids[i]);   // id, deletion state and force_repulsion grow with the vertices: the state of the cells already here survives
+    }
     C->host_dirty = true;
     rc = sync_to_device(C); if (rc != HC_OK) return rc;
   } else {
@@ -222,7 +231,7 @@ int hcp_unpack_cells(hc_cells *C, int type, const int *slots, const long *cell_i
   rc = stage_ints(C, 0, &d_slots, slots, n); if (rc != HC_OK) return rc;
   rc = stage_ints(C, 1, &d_new, is_new, n); if (rc != HC_OK) return rc;
   hipLaunchKernelGGL(unpack_cells_kernel, dim3((unsigned)n), dim3(256), 0, hc::stream(), C->types[type]->host.nv, C->rep_on() ? 12 : 9, (const int *)d_slots, (const int *)d_new,
-                     vert_arrays(C, type), dev_buf, C->L->x0, C->L->nx);
+                     vert_arrays(C, type), dev_buf, C->L->x0, C->L->nx, C->d_env_viol);
   HC_HIP(hipGetLastError());
   return HC_OK;
 }

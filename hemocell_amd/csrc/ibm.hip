@@ -5,8 +5,10 @@
 //   core/hemoCellParticleField.cpp:841-863        spreadParticleForce
 //   core/hemoCellParticleField.cpp:819-839        interpolateFluidVelocity
 #include "cells.h"
+#include <hipcub/hipcub.hpp>
 #include <cstdlib>
 #include <cstring>
+#include <numeric>
 
 namespace {
 
@@ -41,6 +43,56 @@ __global__ __launch_bounds__(256) void ibm_spread_kernel(LatView v, long n, cons
 }
 
 // ----------------------------------------------------------------------------
+// reproducible spread (hc_set_reproducible_spread).  The reference adds particle by particle in storage order
+// (core/hemoCellParticleField.cpp:841-863), so a node's force is a sum in a fixed order and a run repeats bit for bit; the
+// atomic kernels above add in whatever order the hardware takes them.  Here every (particle, admitted stencil node) becomes an
+// entry keyed by its node, written in the canonical order (cell type, cell id, vertex id, stencil node); a stable radix
+// sort by node groups the entries of a node without disturbing that order, and ONE thread per node sums them in sequence and
+// adds the sum to the node.  The order does not depend on the storage slots of the cells, so every slab that holds a node
+// forms the bits the single domain forms.
+__global__ __launch_bounds__(256) void spread_emit_kernel(LatView v, int nv, long n, const int *order, long ebase, const double *px, const double *py,
+                                                          const double *pz, double *fx, double *fy, double *fz, const double *rx, const double *ry,
+                                                          const double *rz, int limit_on, double f_limit, const int *tag, const unsigned char *dead,
+                                                          unsigned int *keys, int *vals, double *c0, double *c1, double *c2) {
+  const long g = (long)blockIdx.x * 256 + threadIdx.x;   // (rank of the cell in id order) * nv + vertex
+  if (g >= n) return;
+  const int cell = order[g / nv];
+  const long i = (long)cell * nv + (g % nv);
+  const long e0 = (ebase + g) * 8;
+  const bool live = tag[cell] != 1 && !dead[i];
+  Stencil s;
+  double f0 = 0.0, f1 = 0.0, f2 = 0.0;
+  if (live) {
+    f0 = fx[i]; f1 = fy[i]; f2 = fz[i];
+    if (limit_on) {  // FORCE_LIMIT cap, core/hemoCellParticleField.cpp:848-852 (mutates sv.force)
+      const double mag = sqrt((f0 * f0 + f1 * f1) + f2 * f2);
+      if (mag > f_limit) { const double sc = f_limit / mag; f0 *= sc; f1 *= sc; f2 *= sc; fx[i] = f0; fy[i] = f1; fz[i] = f2; }
+    }
+    if (rx) { f0 = rx[i] + f0; f1 = ry[i] + f1; f2 = rz[i] + f2; }   // force_repulsion + force, :857-859
+    phi2_stencil(v, px[i], py[i], pz[i], s);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const bool adm = live && s.node[k] >= 0;
+    keys[e0 + k] = adm ? (unsigned int)s.node[k] : 0xffffffffu;
+    vals[e0 + k] = (int)(e0 + k);
+    c0[e0 + k] = adm ? f0 * s.w[k] : 0.0; c1[e0 + k] = adm ? f1 * s.w[k] : 0.0; c2[e0 + k] = adm ? f2 * s.w[k] : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void spread_gather_kernel(LatView v, long n, const unsigned int *keys, const int *vals, const double *c0, const double *c1,
+                                                            const double *c2, double *F) {
+  const long s = (long)blockIdx.x * 256 + threadIdx.x;
+  if (s >= n) return;
+  const unsigned int key = keys[s];
+  if (key == 0xffffffffu || (s > 0 && keys[s - 1] == key)) return;   // not the first entry of its node
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  for (long q = s; q < n && keys[q] == key; q++) { const int e = vals[q]; a0 += c0[e]; a1 += c1[e]; a2 += c2[e]; }
+  v.dirty[key >> 4] = v.epoch;
+  F[key] += a0; F[v.npad + key] += a1; F[2 * v.npad + key] += a2;   // this thread alone touches the node
+}
+
+// ----------------------------------------------------------------------------
 // interpolate: v = sum_j w_j * (j/rho + F/2)(node_j) on the post-stream state
 struct PopView {
   const double *f; const double *F; double bx, by, bz; long qs;   // qs: population stride
@@ -52,6 +104,12 @@ __device__ __forceinline__ void node_velocity(const LatView &v, const PopView &p
   // outside the slab have such a node in their stencil, and their interpolated velocity is never used (the owner's record
   // replaces it, "a local particle wins"), so the value does not matter -- the access must not happen.
   if (v.halo_x && (lx <= -HALO || lx >= v.nx + HALO - 1)) { u[0] = u[1] = u[2] = 0.0; return; }
+  // first halo plane of a slab: the neighbour that owns the node has evaluated this very expression and sent the result
+  // (3 doubles per node instead of the 19 population planes the gather below would need, slab.hip)
+  if (v.halo_x && (lx == -1 || lx == v.nx)) {
+    const double *hu = v.halo_u[lx < 0 ? 0 : 1];
+    if (hu) { const long k = (long)ly * v.nz + lz; u[0] = hu[k]; u[1] = hu[v.ny_nz + k]; u[2] = hu[2L * v.ny_nz + k]; return; }
+  }
   // gather S(node,q) = P(node - c_q, q) with the same wrap rules as the collide kernel
   long xm = -(long)v.plane, xp = (long)v.plane;
   if (v.wrap_x) { if (lx == 0) xm = (long)(v.nx - 1) * v.plane; if (lx == v.nx - 1) xp = -(long)(v.nx - 1) * v.plane; }
@@ -88,6 +146,17 @@ __device__ __forceinline__ void node_velocity(const LatView &v, const PopView &p
   u[0] = jx * invRho + (bx + pv.F[node]) / 2.0;
   u[1] = jy * invRho + (by + pv.F[v.npad + node]) / 2.0;
   u[2] = jz * invRho + (bz + pv.F[2 * v.npad + node]) / 2.0;
+}
+
+// node velocities of one face plane of a slab (lx = 0 or nx - 1), for the neighbour whose first halo plane it is
+__global__ __launch_bounds__(256) void face_velocity_kernel(LatView v, PopView pv, int lx, double *out) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= v.ny_nz) return;
+  const int ly = k / v.nz, lz = k - ly * v.nz;
+  const long node = (long)(lx + HALO) * v.plane + (long)ly * v.nz + lz;
+  double u[3] = {0.0, 0.0, 0.0};
+  if (v.mask[node] == 0) node_velocity(v, pv, lx, ly, lz, node, u);   // stencils admit fluid nodes only
+  out[k] = u[0]; out[v.ny_nz + k] = u[1]; out[2L * v.ny_nz + k] = u[2];
 }
 
 __global__ __launch_bounds__(256) void ibm_interpolate_kernel(LatView v, PopView pv, long n, const double *px, const double *py,
@@ -274,6 +343,7 @@ __device__ __forceinline__ bool tile_is_clear(const LatView &v, const Tile &t, i
     b0[a] = lo >> 3; nb[a] = (hi >> 3) - b0[a] + 1;
   }
   if (!inside) return false;   // uniform: the tile wraps around a periodic face or leaves the addressable range
+  if (nb[0] * nb[1] * nb[2] > 64) return false;   // uniform: a thin, long tile (5832 nodes can span more bricks than one wave looks at) takes the mask path
   if (threadIdx.x < 64) {
     const int l = threadIdx.x;
     bool near = false;
@@ -521,6 +591,67 @@ __global__ __launch_bounds__(256) void ibm_interpolate_cell_kernel(LatView v, Po
 
 static int g_ibm_per_vertex = 0;  // 1: one thread per vertex with direct global atomics (kept for A/B and as reference)
 extern "C" int hc_debug_ibm_per_vertex(int on) { g_ibm_per_vertex = on; return HC_OK; }
+static int g_reproducible = -1;   // -1: not chosen yet (HEMOCELL_REPRODUCIBLE_SPREAD decides at first use)
+static bool reproducible() {
+  if (g_reproducible < 0) { const char *e = std::getenv("HEMOCELL_REPRODUCIBLE_SPREAD"); g_reproducible = (e && *e && *e != '0') ? 1 : 0; }
+  return g_reproducible == 1;
+}
+extern "C" int hc_set_reproducible_spread(int on) { g_reproducible = on ? 1 : 0; return HC_OK; }
+
+// the gather form of the spread: entries -> stable sort by node -> one sequential sum per node
+static int spread_reproducible(hc_cells *C, int force_limit) {
+  const LatView v = make_view(C->L);
+  HC_REQUIRE(v.npad * 3 < 0xffffffffL && C->nverts * 8 < 0x7fffffffL, "reproducible spread: lattice or vertex count beyond its 32-bit keys");
+  const long n_e = C->nverts * 8;
+  if (n_e > C->det_cap) {
+    HC_HIP(hipDeviceSynchronize());
+    for (int k = 0; k < 2; k++) { if (C->det_keys[k]) HC_HIP(hipFree(C->det_keys[k])); if (C->det_vals[k]) HC_HIP(hipFree(C->det_vals[k])); C->det_keys[k] = nullptr; C->det_vals[k] = nullptr; }
+    for (int k = 0; k < 3; k++) { if (C->det_val[k]) HC_HIP(hipFree(C->det_val[k])); C->det_val[k] = nullptr; }
+    if (C->det_tmp) HC_HIP(hipFree(C->det_tmp));
+    C->det_tmp = nullptr; C->det_tmp_bytes = 0;
+    C->det_cap = n_e + n_e / 4 + 4096;
+    for (int k = 0; k < 2; k++) { HC_HIP(hipMalloc((void **)&C->det_keys[k], C->det_cap * sizeof(unsigned int))); HC_HIP(hipMalloc((void **)&C->det_vals[k], C->det_cap * sizeof(int))); }
+    for (int k = 0; k < 3; k++) HC_HIP(hipMalloc((void **)&C->det_val[k], C->det_cap * sizeof(double)));
+    HC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, C->det_tmp_bytes, C->det_keys[0], C->det_keys[1], C->det_vals[0], C->det_vals[1], (int)C->det_cap, 0, 32, hc::stream()));
+    HC_HIP(hipMalloc(&C->det_tmp, C->det_tmp_bytes));
+  }
+  // cell slots in ascending cell id, type by type: the canonical order of the entries
+  std::vector<int> order((size_t)0);
+  std::vector<long> obase((size_t)C->ntypes, 0);
+  for (int t = 0; t < C->ntypes; t++) {
+    const size_t nc = (size_t)C->ncells[t], o = order.size();
+    obase[(size_t)t] = (long)o;
+    order.resize(o + nc);
+    std::iota(order.begin() + (long)o, order.end(), 0);
+    const std::vector<long> &ids = C->hids[t];
+    std::stable_sort(order.begin() + (long)o, order.end(), [&](int a, int b) { return ids[(size_t)a] < ids[(size_t)b]; });
+  }
+  int *d_order = nullptr;
+  int rc = stage_ints(C, 2, &d_order, order.data(), (int)order.size()); if (rc != HC_OK) return rc;
+  long ebase = 0;
+  for (int t = 0; t < C->ntypes; t++) {
+    const int nv = C->types[t]->host.nv;
+    const long n = C->ncells[t] * nv, f = C->first[t];
+    if (n == 0) continue;
+    const bool rep = C->rep_on();
+    hipLaunchKernelGGL(spread_emit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hc::stream(), v, nv, n, (const int *)(d_order + obase[(size_t)t]), ebase,
+                       (const double *)(C->pos[0] + f), (const double *)(C->pos[1] + f), (const double *)(C->pos[2] + f), C->frc[0] + f, C->frc[1] + f, C->frc[2] + f,
+                       rep ? (const double *)(C->rep[0] + f) : nullptr, rep ? (const double *)(C->rep[1] + f) : nullptr, rep ? (const double *)(C->rep[2] + f) : nullptr,
+                       force_limit, C->P.f_limit, (const int *)(C->d_tag + C->cell0[t]), (const unsigned char *)(C->d_vdead + f), C->det_keys[0], C->det_vals[0],
+                       C->det_val[0], C->det_val[1], C->det_val[2]);
+    HC_HIP(hipGetLastError());
+    ebase += n;
+  }
+  // only the bits a node index needs: 2^bits > npad, so the low bits of an invalid key (all ones) still sort behind every node
+  int bits = 1;
+  while (bits < 32 && (1L << bits) <= v.npad) bits++;
+  size_t tmp = C->det_tmp_bytes;
+  HC_HIP(hipcub::DeviceRadixSort::SortPairs(C->det_tmp, tmp, C->det_keys[0], C->det_keys[1], C->det_vals[0], C->det_vals[1], (int)n_e, 0, bits, hc::stream()));
+  hipLaunchKernelGGL(spread_gather_kernel, dim3((unsigned)((n_e + 255) / 256)), dim3(256), 0, hc::stream(), v, n_e, (const unsigned int *)C->det_keys[1],
+                     (const int *)C->det_vals[1], (const double *)C->det_val[0], (const double *)C->det_val[1], (const double *)C->det_val[2], C->L->force[C->L->fcur]);
+  HC_HIP(hipGetLastError());
+  return HC_OK;
+}
 #ifdef HC_IBM_PHASE_TIMES
 extern "C" int hc_debug_phase_times(double *out) {
   unsigned long long h[32];
@@ -539,6 +670,7 @@ int hcp_spread(hc_cells *C, int force_limit) {
   int rc = sync_to_device(C); if (rc != HC_OK) return rc;
   if (C->nverts == 0) return HC_OK;
   hc::ProfScope prof(hc::PK_SPREAD);
+  if (reproducible()) return spread_reproducible(C, force_limit);
   const LatView v = make_view(C->L);
   for (int t = 0; t < C->ntypes; t++) {
     const long n = C->ncells[t] * C->types[t]->host.nv, f = C->first[t];
@@ -587,6 +719,19 @@ int hcp_interpolate(hc_cells *C) {
     }
     HC_HIP(hipGetLastError());
   }
+  return HC_OK;
+}
+
+// the message of a velocity update (slab.hip): u = j/rho + F/2 on this slab's face plane `side`, post-stream state, packed as
+// [3][ny*nz] for the neighbour on that side.  The face plane and the plane behind it have been collided and the halo plane
+// in front of it holds the neighbour's crossing populations.
+int hcl_face_velocity_pack(hc_lattice *L, int side, double *dev_buf) {
+  HC_REQUIRE(L && dev_buf && (side == 0 || side == 1), "hcl_face_velocity_pack: bad arguments");
+  LatView v = make_view(L);
+  v.halo_u[0] = v.halo_u[1] = nullptr;   // own planes only: nothing here reads a halo velocity
+  PopView pv{L->f[L->cur], L->force[(L->fcur + 2) % 3], L->body[0], L->body[1], L->body[2], (long)L->qstride, L->regions};
+  hipLaunchKernelGGL(face_velocity_kernel, dim3((unsigned)((L->plane + 255) / 256)), dim3(256), 0, hc::stream(), v, pv, side == 0 ? 0 : L->nx - 1, dev_buf);
+  HC_HIP(hipGetLastError());
   return HC_OK;
 }
 

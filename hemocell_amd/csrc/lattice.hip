@@ -737,6 +737,7 @@ int hcl_collide_stream_part(hc_lattice *L, int part) {
 int hcl_step_end(hc_lattice *L) {
   HC_REQUIRE(L, "hcl_step_end: null lattice");
   L->cur ^= 1; L->fcur = (L->fcur + 1) % 3;
+  L->halo_u_valid = false;   // velocities of a neighbour's face plane belong to the state that has just been replaced
   L->fepoch[L->fcur] = (uint8_t)(L->fepoch[L->fcur] % 255 + 1);   // the buffer spread will add to next gets a fresh epoch (1..255)
   return HC_OK;
 }

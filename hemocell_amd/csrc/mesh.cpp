@@ -276,6 +276,12 @@ std::string build_cell_tables(CellTables &T, int model, int shape, const hc_para
       vol += dot(V[tr[0]], cross(V[tr[1]], V[tr[2]])) / 6.0 / 3.0;
     }
   T.volume_eq = vol;
+  {   // diameter of the undeformed mesh (twice the largest distance from its bounding-box centre): sizes the particle envelope of slab runs
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, r2 = 0.0;
+    for (const Vec3 &v : T.vertices) for (int d = 0; d < 3; d++) { lo[d] = std::min(lo[d], v[d]); hi[d] = std::max(hi[d], v[d]); }
+    for (const Vec3 &v : T.vertices) { double q = 0; for (int d = 0; d < 3; d++) { const double c = v[d] - 0.5 * (lo[d] + hi[d]); q += c * c; } r2 = std::max(r2, q); }
+    T.diameter = 2.0 * std::sqrt(r2);
+  }
   double s = 0; for (double a : T.triangle_area_eq) s += a; T.area_mean_eq = s / nt;
   s = 0; for (double l : T.edge_length_eq) s += l; T.edge_mean_eq = s / ne;
   s = 0; for (double a : T.edge_angle_eq) s += a; T.angle_mean_eq = s / ne;

@@ -22,6 +22,7 @@ struct CellTables {
   std::vector<std::array<long, 2>> inner_edges;
   std::vector<double> inner_edge_length_eq;
   double volume_eq = 0, area_mean_eq = 0, edge_mean_eq = 0, angle_mean_eq = 0;
+  double diameter = 0;                         // of the undeformed mesh, lattice units
   double k_volume = 0, k_area = 0, k_link = 0, k_bend = 0, eta_m = 0;
 
   // ---- gather form used by the kernels (all int32, -1 padded) ----

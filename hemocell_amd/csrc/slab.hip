@@ -12,7 +12,7 @@
 // collective is on the stepping path.  Per step the 5 populations with c_x = +-1 of each face plane cross (width-1
 // message); at a velocity update the neighbour also needs what lets it evaluate node velocities on its first halo plane
 // (width-2 message: the face plane's 19 populations and the 5 of the plane behind it that stream onto that halo plane),
-// and the cells within E_SHARE lattice units of a face are replicated on the neighbour as the reference's envelope copies
+// and the cells within hc_cells::e_share lattice units of a face (hcp_set_envelope) are replicated on the neighbour as the reference's envelope copies
 // are.  Every rank interpolates only the particles whose nearest node it owns; a record of 9 (12 with a repulsion) doubles per
 // particle carries position, velocity and force to the other holder, where "a local particle wins" decides what is kept.
 //
@@ -46,7 +46,8 @@ struct Slab {
   bool planned = false;                      // the cell extents for the coming envelope sync are on their way to the host
   // envelope synchronisation: id headers [side][type][MAX_HDR] (pinned staging, device send / receive, pinned landing)
   long *h_hdr_s = nullptr, *h_hdr_r = nullptr, *d_hdr_s = nullptr, *d_hdr_r = nullptr; int hdr_types = 0;
-  hipEvent_t hdr_ev = nullptr, rec_ready = nullptr, rec_done = nullptr, halo_packed = nullptr, halo_arrived = nullptr;
+  hipEvent_t hdr_ev = nullptr, rec_ready = nullptr, rec_done = nullptr, halo_packed = nullptr, halo_arrived = nullptr, u_packed = nullptr, u_arrived = nullptr;
+  double *us[2] = {nullptr, nullptr};         // face-plane velocities on their way to the neighbours ([side][3][plane]; they land in L->halo_u)
   double *d_rec_s[2] = {nullptr, nullptr}, *d_rec_r[2] = {nullptr, nullptr}; size_t rec_cap_s[2] = {0, 0}, rec_cap_r[2] = {0, 0};
   double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
@@ -71,10 +72,21 @@ int make_slab(hc_lattice *L, hc_cells *C, Slab **out) {
     HC_HIP(hipEventCreateWithFlags(&S->rec_done, hipEventDisableTiming));
     HC_HIP(hipEventCreateWithFlags(&S->halo_packed, hipEventDisableTiming));
     HC_HIP(hipEventCreateWithFlags(&S->halo_arrived, hipEventDisableTiming));
+    HC_HIP(hipEventCreateWithFlags(&S->u_packed, hipEventDisableTiming));
+    HC_HIP(hipEventCreateWithFlags(&S->u_arrived, hipEventDisableTiming));
+    for (int side = 0; side < 2; side++) {
+      HC_HIP(hipMalloc((void **)&S->us[side], 3 * L->plane * sizeof(double)));
+      HC_HIP(hipMalloc((void **)&L->halo_u[side], 3 * L->plane * sizeof(double)));
+      HC_HIP(hipMemset(L->halo_u[side], 0, 3 * L->plane * sizeof(double)));
+    }
+    L->halo_u_valid = false;
     g_slabs[L] = S;
   }
   if (C) {
-    if (C->ntypes > 0 && L->nx < 40) { hc::set_error("a slab that carries cells must be at least 40 planes wide (two cell diameters plus the envelope), got " + std::to_string(L->nx)); return HC_ERR_ARG; }
+    double dmax = 0.0;
+    for (int t = 0; t < C->ntypes; t++) dmax = std::max(dmax, C->types[t]->host.diameter);
+    const int need = (int)std::ceil(2.0 * dmax + 2.0 * C->e_share);   // 40 planes for an RBC at dx = 0.5 um with the default envelope
+    if (C->ntypes > 0 && L->nx < need) { hc::set_error("a slab that carries cells must be at least " + std::to_string(need) + " planes wide (two cell diameters plus the particle envelope on both faces), got " + std::to_string(L->nx)); return HC_ERR_ARG; }
     S->C = C;
     if (S->hdr_types < C->ntypes) {
       HC_HIP(hipDeviceSynchronize());
@@ -143,10 +155,40 @@ int halo_make_fresh(Slab *S, int width) {
   return halo_finish(S);
 }
 
+// The message of a velocity update.  The interpolation blends node velocities u = j/rho + F/2 (Cell::computeVelocity) over a
+// particle's stencil, and a particle next to a face has stencil nodes on the neighbour's face plane.  Each rank evaluates u on
+// its two face planes -- it owns every population that streams there once the crossing populations of the step have arrived --
+// and sends the result: 3 planes of doubles per face instead of the 19 population planes from which the receiver could
+// form the same expression itself (round 2; 1.5 MB instead of 10 MB per direction at 256 x 256).  On the stream in use: pack;
+// on the transfer stream: the exchange into L->halo_u; the caller waits for u_arrived before it interpolates.
+int velocity_exchange(Slab *S) {
+  hc_lattice *L = S->L;
+  int lo, hi; hcm::neighbours(periodic_x(L), lo, hi);
+  int rc;
+  if (lo >= 0) { rc = hcl_face_velocity_pack(L, 0, S->us[0]); if (rc != HC_OK) return rc; }
+  if (hi >= 0) { rc = hcl_face_velocity_pack(L, 1, S->us[1]); if (rc != HC_OK) return rc; }
+  const hipStream_t X = transfer_stream();
+  if (X != hc::stream()) {
+    HC_HIP(hipEventRecord(S->u_packed, hc::stream()));   // also: every kernel that read the previous velocities precedes this point
+    HC_HIP(hipStreamWaitEvent(X, S->u_packed, 0));
+  }
+  const size_t bytes = 3 * L->plane * sizeof(double);
+  rc = hcm::exchange(X, periodic_x(L), S->us[0], bytes, S->us[1], bytes, L->halo_u[0], bytes, L->halo_u[1], bytes);
+  if (rc != HC_OK) return rc;
+  if (X != hc::stream()) HC_HIP(hipEventRecord(S->u_arrived, X));
+  L->halo_u_valid = true;
+  return HC_OK;
+}
+int velocity_wait(Slab *S) {   // on the stream in use, before anything interpolates
+  if (transfer_stream() != hc::stream()) HC_HIP(hipStreamWaitEvent(hc::stream(), S->u_arrived, 0));
+  return HC_OK;
+}
+
 // ---------------------------------------------------------------------------- particle envelopes
 struct Plan {                                // one cell type at one envelope synchronisation
   std::vector<int> send[2];                  // slots of the cells that cross the low / high face, ordered by cell id
   std::vector<int> gone;                     // slots of local cells that were deleted at a wall since the last synchronisation
+  std::vector<long> gone_before;             // ids of cells this rank already compacted away since then (hc_cells::slab_gone)
   std::vector<long> ids_r[2], tag_r[2];      // what the neighbours announced: crossing cells, deleted cells
   std::vector<double> ext;                   // [n][4] extents of the local cells
   long n = 0;
@@ -178,18 +220,20 @@ int sync_begin(Slab *S, std::vector<Plan> &plans) {
       const double *e = &P.ext[(size_t)(4 * c)];
       if (e[3] != 0.0) { P.gone.push_back((int)c); continue; }
       if (e[2] <= 0.0) continue;   // only a rank that owns part of the cell forwards it (a pure ghost is its owner's business)
-      if (lo >= 0 && e[0] < x0 + E_SHARE) P.send[0].push_back((int)c);
-      if (hi >= 0 && e[1] >= x1 - E_SHARE) P.send[1].push_back((int)c);
+      if (lo >= 0 && e[0] < x0 + C->e_share) P.send[0].push_back((int)c);
+      if (hi >= 0 && e[1] >= x1 - C->e_share) P.send[1].push_back((int)c);
     }
+    P.gone_before.swap(C->slab_gone[t]); C->slab_gone[t].clear();
     for (int side = 0; side < 2; side++) {
       std::stable_sort(P.send[side].begin(), P.send[side].end(), [&](int a, int b) { return ids[(size_t)a] < ids[(size_t)b]; });
-      const size_t k = P.send[side].size(), g = P.gone.size();
-      if (k + g + 2 > (size_t)MAX_HDR) { hc::set_error("more cells cross one slab face (" + std::to_string(k) + ") than the id header holds"); return HC_ERR_STATE; }
+      const size_t k = P.send[side].size(), g = P.gone.size(), gb = P.gone_before.size();
+      if (k + g + gb + 2 > (size_t)MAX_HDR) { hc::set_error("more cells cross one slab face (" + std::to_string(k) + ") than the id header holds"); return HC_ERR_STATE; }
       long *h = S->h_hdr_s + ((size_t)side * C->ntypes + t) * MAX_HDR;
       h[0] = (long)k;
       for (size_t i = 0; i < k; i++) h[1 + i] = ids[(size_t)P.send[side][i]];
-      h[1 + k] = (long)g;
+      h[1 + k] = (long)(g + gb);
       for (size_t i = 0; i < g; i++) h[2 + k + i] = ids[(size_t)P.gone[i]];
+      for (size_t i = 0; i < gb; i++) h[2 + k + g + i] = P.gone_before[i];
     }
   }
   S->stats[6] += wall_s() - t_wait;
@@ -289,6 +333,10 @@ int sync_merge(Slab *S, std::vector<Plan> &plans, hipStream_t comm_stream) {
     for (long c = 0; c < n; c++) known[C->hids[t][(size_t)c]] = c;
     std::vector<char> refreshed((size_t)n, 0);
     long next_new = n;
+    // a neighbour that has not heard yet still sends its copy of a cell this rank compacted away: it lands in a new slot
+    // (the records of one message are contiguous) and leaves again with the drop list below
+    const std::unordered_set<long> gone_before(P.gone_before.begin(), P.gone_before.end());
+    std::vector<int> drop;
     for (int side = 0; side < 2; side++) {
       const std::vector<long> &rid = P.ids_r[side];
       if (rid.empty()) continue;
@@ -296,7 +344,10 @@ int sync_merge(Slab *S, std::vector<Plan> &plans, hipStream_t comm_stream) {
       for (size_t i = 0; i < rid.size(); i++) {
         auto f = known.find(rid[i]);
         if (f != known.end()) { slots[i] = (int)f->second; is_new[i] = 0; if (f->second < n) refreshed[(size_t)f->second] = 1; }
-        else { slots[i] = (int)next_new; is_new[i] = 1; known[rid[i]] = next_new++; S->stats[1] += 1.0; }
+        else {
+          slots[i] = (int)next_new; is_new[i] = 1; known[rid[i]] = next_new++;
+          if (!gone_before.empty() && gone_before.count(rid[i])) drop.push_back(slots[i]); else S->stats[1] += 1.0;
+        }
       }
       const int rc = hcp_unpack_cells(C, t, slots.data(), rid.data(), is_new.data(), (int)rid.size(), S->d_rec_r[side] + off[side]);
       if (rc != HC_OK) return rc;
@@ -306,7 +357,6 @@ int sync_merge(Slab *S, std::vector<Plan> &plans, hipStream_t comm_stream) {
     // core/hemoCellFields.cpp:676-688); a cell that reached a wall -- here or on the neighbour that also holds it -- goes everywhere
     std::unordered_set<long> dead_ids;
     for (int side = 0; side < 2; side++) for (long id : P.tag_r[side]) dead_ids.insert(id);
-    std::vector<int> drop;
     for (long c = 0; c < n; c++) {
       const double *e = &P.ext[(size_t)(4 * c)];
       const bool gone = e[3] != 0.0, told = !dead_ids.empty() && dead_ids.count(C->hids[t][(size_t)c]) > 0;
@@ -350,7 +400,8 @@ int step(Slab *S, hc_cells *C, long it, int k_p, int force_limit, bool more) {
     TRY(hcl_collide_stream_part(L, 0));                                          // :317
     hcl_step_end(L); S->halo_fresh = false;
     if (particle_step) {
-      TRY(halo_make_fresh(S, 2));
+      TRY(halo_make_fresh(S, 1));
+      TRY(velocity_exchange(S)); TRY(velocity_wait(S));
       TRY(sync_begin(S, plans));
       TRY(sync_records(S, plans, hc::stream()));
       TRY(hcp_interpolate(C));                                                   // :327-332
@@ -363,19 +414,21 @@ int step(Slab *S, hc_cells *C, long it, int k_p, int force_limit, bool more) {
     hc::route(1);
     TRY(halo_make_fresh(S, 1));                    // the neighbours' faces (on their way since the previous step)
     TRY(hcl_collide_stream_part(L, 4));            // the two planes next to each face, beside the interior ...
-    TRY(halo_begin(S, 2, 1));                      // ... so that the wide message travels during the interior collide
+    TRY(halo_begin(S, 1, 1));                      // ... so that the crossing populations travel during the interior collide
     hc::route(0);
     TRY(hcl_collide_stream_part(L, 3));            // main stream: planes 2 .. nx-3
     hcl_step_end(L);
     hc::route(1);
-    TRY(halo_finish(S));                           // wide faces of the neighbours -> halo planes of the new state
+    TRY(halo_finish(S));                           // the neighbours' crossing populations -> halo planes of the new state
+    TRY(velocity_exchange(S));                     // node velocities of my face planes (they read planes -1 .. 1) -> the neighbours' first halo plane
     TRY(hc::join());
+    TRY(velocity_wait(S));
     TRY(sync_records(S, plans, transfer_stream()));   // crossing cells interpolated first; their records leave on the transfer stream
     TRY(hcp_interpolate(C));                       // :327-332, all cells, while the records travel
     TRY(sync_merge(S, plans, transfer_stream()));
     TRY(hcp_advance(C, 0));                        // :342
     TRY(hcp_mechanics(C, it, 0));                  // :345
-    S->halo_fresh = true;                          // width 2 covers what the next collide reads
+    S->halo_fresh = true;                          // the crossing populations are what the next collide reads
   } else {
     TRY(hc::fork());
     TRY(hcl_collide_stream_part(L, 1));            // main stream: the planes that read no halo data
@@ -413,6 +466,11 @@ int run(hc_lattice *L, hc_cells *C, long *iter, int n, int k_p, int force_limit)
     if (iter) *iter = it + 1;
   }
   S->stats[4] += (double)n; S->stats[5] += wall_s() - t0;
+  if (C && C->h_env_viol && *C->h_env_viol != 0) {   // written by the merge kernels that have completed so far; a late one is seen by the next call
+    hc::set_error("particle envelope too small: " + std::to_string(*C->h_env_viol) + " particle(s) had crossed a slab face before a copy of their cell existed on the "
+                  "neighbour (envelope " + std::to_string(C->e_share) + " lu per velocity update; raise <particleEnvelope> or lower stepParticleEvery)");
+    return HC_ERR_STATE;
+  }
   return HC_OK;
 }
 
@@ -443,7 +501,9 @@ void lattice_destroyed(hc_lattice *L) {
   if (S->d_hdr_s) hipFree(S->d_hdr_s);
   if (S->d_hdr_r) hipFree(S->d_hdr_r);
   for (int side = 0; side < 2; side++) { if (S->d_rec_s[side]) hipFree(S->d_rec_s[side]); if (S->d_rec_r[side]) hipFree(S->d_rec_r[side]); }
-  for (hipEvent_t e : {S->hdr_ev, S->rec_ready, S->rec_done, S->halo_packed, S->halo_arrived}) if (e) hipEventDestroy(e);
+  for (hipEvent_t e : {S->hdr_ev, S->rec_ready, S->rec_done, S->halo_packed, S->halo_arrived, S->u_packed, S->u_arrived}) if (e) hipEventDestroy(e);
+  for (int side = 0; side < 2; side++) { if (S->us[side]) hipFree(S->us[side]); if (L->halo_u[side]) hipFree(L->halo_u[side]); L->halo_u[side] = nullptr; }
+  L->halo_u_valid = false;
   delete S;
   g_slabs.erase(it);
 }

@@ -81,6 +81,19 @@ class SlabRunner:
     def add_cell_type(self, celltype):
         return self.cells.addCellType(celltype, self.k_m)
 
+    def set_envelope(self, particle_envelope_lu):
+        """<domain><particleEnvelope> of the configuration (core/hemoCell.cpp:139), after the cell types and before the cells;
+        returns the distance from a slab face within which whole cells are replicated"""
+        used = C.c_double()
+        host.check(host.capi.lib().hcp_set_envelope(self.cells.ptr, float(particle_envelope_lu), C.byref(used)))
+        return used.value
+
+    def envelope(self):
+        """(share in use [lu], copies that arrived late so far)"""
+        used, late = C.c_double(), C.c_long()
+        host.check(host.capi.lib().hcp_envelope(self.cells.ptr, C.byref(used), C.byref(late)))
+        return used.value, late.value
+
     def load_cells(self, t, centres, angles, min_dist_um=0.0):
         """offer every cell to this rank (hcp_add_cell keeps what its slab has to hold, periodic images included);
         call sync_placement() after the last type.  Returns the number of cells kept on this rank."""

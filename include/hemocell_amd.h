@@ -65,6 +65,13 @@ int hc_profile_reset(void);
 const char *hc_build_tag(void);
 /* device-to-device copy of `bytes` on the library stream, `repeats` times: read + written GB/s of the GPU in hand */
 int hc_measure_copy_bandwidth(size_t bytes, int repeats, double *gbytes_per_s);
+/* Reproducible force spreading.  The reference adds the particles' forces to the lattice particle by particle, in storage
+ * order (core/hemoCellParticleField.cpp:841-863): a run repeats bit for bit.  The default kernels here add with fp64 atomics in
+ * whatever order the hardware takes them, so two runs of one input differ in the last bits.  on = 1 selects the gather form:
+ * every (particle, stencil node) contribution is keyed by its node, sorted stably in (cell type, cell id, vertex id) order and
+ * summed by one thread per node -- identical bits from run to run and from one slab decomposition to another, at several times
+ * the cost of the atomic kernel.  Also selected by HEMOCELL_REPRODUCIBLE_SPREAD=1 in the environment. */
+int hc_set_reproducible_spread(int on);
 /* A/B switch: 1 = per-vertex IBM kernels with direct global atomics instead of the LDS-tiled per-cell kernels */
 int hc_debug_ibm_per_vertex(int on);
 int hc_debug_force_plane_padding(int on); /* tests / A-B runs: lattices created afterwards get the padded x-plane stride whatever their size (1), never (-1), by size (0, default) */
@@ -175,6 +182,11 @@ int hcl_halo_unpack(hc_lattice *L, int side, int width, const double *dev_buf);
 /* as hcl_halo_pack, but from the buffer the collide-stream in progress is writing (between
  * hcl_collide_stream_part(L, 4) and hcl_step_end): lets the message leave before the interior planes are done */
 int hcl_halo_pack_next(hc_lattice *L, int side, int width, double *dev_buf);
+/* the message of a velocity update between slabs: node velocities u = j/rho + F/2 (Cell::computeVelocity for
+ * ExternalForceDynamics, what core/hemoCellParticleField.cpp:833 blends) of this slab's face plane `side`, evaluated by
+ * their owner on the post-stream state and packed as [3][ny*nz] doubles (device pointer) for the neighbour whose first halo
+ * plane it is -- 3 planes instead of the 19 population planes of a width-2 halo.  hc_iterate exchanges them itself. */
+int hcl_face_velocity_pack(hc_lattice *L, int side, double *dev_buf);
 int hcl_dims(const hc_lattice *L, int dims[3]);
 /* counts[0] = bulk nodes of this slab, [1] = fluid nodes (GuoExternalForceBGKdynamics), [2] = nodes the collide kernel
  * loads and stores (everything but solid nodes without a fluid neighbour, which full-way bounce-back leaves inert) */
@@ -240,6 +252,17 @@ int hcp_add_cell_unchecked(hc_cells *C, int type, long cell_id, const double cen
 /* n_vertices counts the listed vertices (cells x vertices per cell; an incomplete cell keeps its slots), n_deleted the
  * cells removed entirely so far */
 int hcp_slab_sync_placement(hc_cells *C, long *global_cells_per_type /*[n types]*/);
+/* The particle envelope of a slab run: <particleEnvelope> of the case configuration in lattice units
+ * (examples/pipeflow/config.xml:34), read at core/hemoCell.cpp:139 and handed to HemoCellFields (core/hemoCellFields.cpp:39-43).
+ * The reference replicates single particles within that distance of a block face on the neighbour; here whole cells are
+ * replicated, so an envelope E acts as share = E - (diameter of the largest cell type): how far a cell may still travel
+ * towards the face, between two velocity updates, before a complete copy must exist on the other side (default share: 4 lu).
+ * Call after the cell types are added and before the first cell is placed.  A request the slab width cannot support
+ * (nx >= 2 * diameter + 2 * share) is clamped and the share in use returned; a slab too thin for the minimum (2 lu) is an
+ * error.  Every copy that arrives late -- a particle already within reach of the receiving slab's nodes when its cell first
+ * gets there -- is counted on the device (hcp_envelope) and fails the hc_iterate call that notices it. */
+int hcp_set_envelope(hc_cells *C, double particle_envelope_lu, double *share_in_use);
+int hcp_envelope(const hc_cells *C, double *share_in_use, long *late_copies);
 int hcp_counts(hc_cells *C, long *n_vertices, long *n_cells, long *n_deleted);
 int hcp_type_range(hc_cells *C, int type, long *first_vertex, long *n_cells);
 /* What happens to a particle whose nearest node is a boundary after advance (core/hemoCellParticleField.cpp:566-588):

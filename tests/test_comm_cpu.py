@@ -70,6 +70,13 @@ def _mesh_worker(rank, world, port, periodic, q):
         blob = np.arange(128, dtype=np.uint8) if rank == 0 else np.zeros(128, dtype=np.uint8)
         check(lib.hc_comm_bcast(blob.ctypes.data, 128, 0))
         assert np.array_equal(blob, np.arange(128, dtype=np.uint8))
+        # ---- all-gather of a placement-sized block (hcp_slab_sync_placement gathers (type, id) pairs of rejected cells: with the
+        # 15 500 cells of an 8 x 256^3 pipe that is up to 248 KB per rank), every rank sees every block in rank order
+        mine = np.full(31_000, rank, dtype=np.int64) + np.arange(31_000) * 1000
+        everyone = np.zeros(31_000 * world, dtype=np.int64)
+        check(lib.hc_comm_allgather(mine.ctypes.data, mine.nbytes, everyone.ctypes.data))
+        for k in range(world):
+            assert np.array_equal(everyone[k * 31_000:(k + 1) * 31_000], np.full(31_000, k, dtype=np.int64) + np.arange(31_000) * 1000)
         check(lib.hc_comm_barrier())
         check(lib.hc_comm_finalize())
         q.put((rank, "ok"))

@@ -265,6 +265,40 @@ def _launch_ranks(exe, args, cwd, world, salt=0):
     return outs
 
 
+def test_checkpoint_with_an_incomplete_cell_and_a_truncated_dump(tmp_path, gpu):
+    """ADVICE round 2 (hemocell.h saveCheckPoint / loadCheckPoint): a dump written while a cell has lost particles at a wall
+    loads again and the remnant is removed as the reference's load path does (core/hemoCellFields.cpp:272-274:
+    load, syncEnvelopes, deleteIncompleteCells); a truncated dump is refused with a log line and exit(1)"""
+    exe = _build(tmp_path, "tests/drivers/checkpoint_incomplete.cpp")
+    d = str(tmp_path / "case"); shutil.copytree(os.path.join(ROOT, "tests", "golden", "shear_case"), d)
+    for f in os.listdir(d):
+        os.chmod(os.path.join(d, f), 0o644)
+    open(os.path.join(d, "RBC.pos"), "w").write("2\n15.0 8.25 8.25 90 0 0\n34.5 8.25 12.5 90 0 0\n")     # lu: (30, 16.5, 16.5) and (69, 16.5, 25)
+    r = subprocess.run([exe, "config.xml", "save"], cwd=d, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    before = [l.split() for l in r.stdout.splitlines() if l.startswith("BEFORE")][0]
+    assert int(before[2]) == 2 and int(before[4]) == 1 and int(before[6]) > 0          # two cells, one incomplete, particles missing
+    resumed = [l.split() for l in r.stdout.splitlines() if l.startswith("RESUMED")][0]
+    assert int(resumed[2]) == 56 and int(resumed[4]) == 1 and int(resumed[6]) == 0 and int(resumed[8]) == 0
+    assert "CONTINUED iteration 64 cells 1" in r.stdout
+    ck = os.path.join(d, "tmp", "checkpoint", "checkpoint.bin")
+    assert os.path.exists(ck) and not os.path.exists(ck + ".tmp")
+    size = os.path.getsize(ck)
+    for cut in (size - 1000, size // 2, 40):                                            # inside the records, the populations, the header
+        with open(ck, "rb") as fh:
+            blob = fh.read()
+        with open(ck, "wb") as fh:
+            fh.write(blob[:cut])
+        # checkpoint.xml as the configuration, as the reference resumes: the run goes back to the directory the dump names
+        r2 = subprocess.run([exe, "tmp/checkpoint/checkpoint.xml", "load"], cwd=d, capture_output=True, text=True, timeout=600)
+        assert r2.returncode == 1 and "truncated or damaged" in r2.stdout + r2.stderr, (cut, r2.returncode, r2.stdout[-1500:])
+        assert "RESUMED" not in r2.stdout
+        with open(ck, "wb") as fh:
+            fh.write(blob)
+    r3 = subprocess.run([exe, "tmp/checkpoint/checkpoint.xml", "load"], cwd=d, capture_output=True, text=True, timeout=600)     # the intact dump still loads
+    assert r3.returncode == 0 and "RESUMED iteration 56 cells 1" in r3.stdout, r3.stdout[-1500:]
+
+
 def test_two_rank_checkpoint_and_resume(tmp_path, gpu):
     """core/hemoCellFields.cpp:240-319 with two ranks: every rank dumps its block (checkpoint.<rank>.bin), a restart of two ranks
     from the iteration-200 dump prints the remaining statistics of the uninterrupted two-rank run, digit for digit"""

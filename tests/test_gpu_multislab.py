@@ -32,7 +32,7 @@ WALL_CELLS = [((30.0, 16.5, 16.5), (90, 0, 0)), ((69.0, 16.5, 25.0), (90, 0, 0))
 REPULSION = dict(k=2e-6, cutoff_um=0.7, k_b=3e-6, b_cutoff_um=1.0)   # examples/pipeflow/config.xml:36-38 magnitudes
 
 
-def _build(rank, world, rep=False, padded=False, cells=CELLS, plts=PLTS, force=FORCE, nxg=NXG, del_mode=None, k_p=K_P, push=None, regions=None):
+def _build(rank, world, rep=False, padded=False, cells=CELLS, plts=PLTS, force=FORCE, nxg=NXG, del_mode=None, k_p=K_P, push=None, regions=None, envelope=None):
     from hemocell_amd import host
     from hemocell_amd.slab import SlabRunner
     host.check(host.capi.lib().hc_debug_force_plane_padding(1 if padded else 0))   # padded x-plane stride (hc_lattice::xs)
@@ -49,6 +49,8 @@ def _build(rank, world, rep=False, padded=False, cells=CELLS, plts=PLTS, force=F
     r.add_cell_type(host.CellType.plt(P))
     if del_mode:
         r.cells.setDeletionMode(del_mode)
+    if envelope is not None:
+        r.share = r.set_envelope(envelope)
     r.load_cells(0, [np.array(c) for c, _ in cells], [np.array(a) for _, a in cells])
     r.load_cells(1, [np.array(c) for c, _ in plts], [np.array(a) for _, a in plts])
     placed = r.sync_placement()
@@ -60,18 +62,25 @@ def _build(rank, world, rep=False, padded=False, cells=CELLS, plts=PLTS, force=F
     return r, mask
 
 
-def _run(r, steps, push):
+def _run(r, steps, push, query_at=None):
     """push = (cell id, velocity): after iteration 0 has interpolated, that cell gets a held velocity (velocities are only
-    refreshed every stepParticleEvery iterations) -- the IBM itself never lets a membrane reach a no-slip wall"""
+    refreshed every stepParticleEvery iterations) -- the IBM itself never lets a membrane reach a no-slip wall.
+    query_at: after that many iterations the host looks at the cells the way HemoCell::writeOutput does
+    (deleteIncompleteCells + counts: this rank compacts its gone cells away on its own, between two synchronisations)"""
     if push is None:
         r.run(steps)
         return
     r.run(1)
     ids = r.cells.cell_ids()
-    vel = r.cells.velocities.reshape(len(ids), -1, 3)     # RBC only in these cases
-    vel[ids == push[0]] = np.array(push[1])
-    r.cells.velocities = vel.reshape(-1, 3)
-    r.run(steps - 1)
+    if len(ids):                                          # a slab may hold no cell at all
+        vel = r.cells.velocities.reshape(len(ids), -1, 3)     # RBC only in these cases
+        vel[ids == push[0]] = np.array(push[1])
+        r.cells.velocities = vel.reshape(-1, 3)
+    done = 1
+    if query_at is not None:
+        r.run(query_at - done); done = query_at
+        r.cells.deleteIncompleteCells(); r.cells.counts()
+    r.run(steps - done)
 
 
 def _worker(rank, world, port, out, kw, steps, q):
@@ -79,15 +88,24 @@ def _worker(rank, world, port, out, kw, steps, q):
         sys.path.insert(0, ROOT)
         from hemocell_amd import host, slab
         slab.comm_init(rank, world, local_rank=0, port=port, transport="tcp")   # every rank on GPU 0
-        push = kw.pop("push", None)
+        push = kw.pop("push", None); query_at = kw.pop("query_at", None)
+        if rank != 0:
+            query_at = None          # only rank 0 looks: the asymmetric case (the other holder still has its copy)
+        expect_error = kw.pop("expect_error", False)
         r, _ = _build(rank, world, **kw)
-        _run(r, steps, push)
+        error = ""
+        try:
+            _run(r, steps, push, query_at)
+        except host.HcError as e:          # host.check raises it with hc_last_error()
+            if not expect_error:
+                raise
+            error = str(e)
         cid, vid, pos = r.owned_vertex_table(0)
         pcid, pvid, ppos = r.owned_vertex_table(1)
         gstats = (r.fluid_stats(0), r.vertex_stats(1), r.vertex_stats(2))    # reduced: every rank gets the global numbers
         np.savez(os.path.join(out, "r%d.npz" % rank), f=r.populations(), cid=cid, vid=vid, pos=pos, pcid=pcid, pvid=pvid, ppos=ppos,
                  held=r.cells.counts()[1], gstats=np.array(gstats), stats=np.array(list(r.slab_stats().values())),
-                 deleted=r.cells.counts()[2])
+                 deleted=r.cells.counts()[2], error=np.array(error), envelope=np.array(r.envelope()))
         slab.barrier()
         slab.comm_finalize()
         q.put((rank, "ok"))
@@ -124,10 +142,60 @@ def _initial_x():
     return x
 
 
+@pytest.fixture
+def reproducible_spread(gpu):
+    """hc_set_reproducible_spread for this process and, through the environment, for the ranks it spawns"""
+    os.environ["HEMOCELL_REPRODUCIBLE_SPREAD"] = "1"
+    gpu.check(gpu.capi.lib().hc_set_reproducible_spread(1))
+    yield
+    del os.environ["HEMOCELL_REPRODUCIBLE_SPREAD"]
+    gpu.check(gpu.capi.lib().hc_set_reproducible_spread(0))
+
+
+# the cells of CELLS / PLTS that stay clear of the periodic seam during the run: a cell across the seam lives on one slab as
+# its periodic image, 144 lu away, where x + v rounds in other bits than at the unshifted position (the reference shifts
+# its envelope copies the same way, core/hemoCellParticleDataTransfer.cpp:33-65); those cases keep a tolerance (below)
+INNER_CELLS, INNER_PLTS = [CELLS[k] for k in (0, 1, 3, 4, 5)], [PLTS[k] for k in (0, 1)]
+
+
+@pytest.mark.parametrize("world,padded,seam", [(2, False, False), (3, False, False), (4, False, False), (2, True, False), (2, False, True), (3, False, True)])
+def test_slabs_equal_single_domain_bit_for_bit(tmp_path, gpu, reproducible_spread, world, padded, seam):
+    """with the reproducible spread (sums in cell-id order, whatever slot a cell sits in) N slabs give the BITS of the single
+    domain: populations and vertex positions after 250 iterations, copies created and dropped at the interior faces on the way --
+    what the reference's CI asks of its rank counts (scripts/ci/pipeflow_sanity.sh:25-33), here without any tolerance.
+    seam: with the two cells that cross the periodic seam as well; their images round differently (above), the rest of the
+    difference the atomic spread showed is gone: 1e-12 where test_slabs_match_single_domain needs 5e-12"""
+    nxg = 192 if world == 4 else NXG
+    kw = dict(nxg=nxg) if seam else dict(nxg=nxg, cells=INNER_CELLS, plts=INNER_PLTS)
+    cells, plts = (CELLS, PLTS) if seam else (INNER_CELLS, INNER_PLTS)
+    res = _spawn(world, tmp_path, dict(kw, padded=padded), salt=60 + padded + 2 * seam)
+    ref, mask = _build(0, 1, **kw)
+    ref.run(STEPS)
+    f_ref = ref.lattice.populations().reshape(nxg, NY * NZ, 19)
+    f_all = np.concatenate([r["f"].reshape(nxg // world, NY * NZ, 19) for r in res], axis=0)
+    fluid = (mask.reshape(nxg, NY * NZ) == 0)
+    allpos = ref.cells.positions
+    nrbc = len(cells) * 642
+    worst = 0.0
+    for key, p_ref in ((("cid", "vid", "pos"), allpos[:nrbc].reshape(len(cells), -1, 3)), (("pcid", "pvid", "ppos"), allpos[nrbc:].reshape(len(plts), -1, 3))):
+        for r in res:
+            d = r[key[2]] - p_ref[r[key[0]], r[key[1]]]
+            if seam:
+                d[:, 0] = (d[:, 0] + nxg / 2) % nxg - nxg / 2
+            worst = max(worst, np.abs(d).max() if len(d) else 0.0)
+    err_f = np.abs(f_all - f_ref)[fluid].max()
+    print("slabs vs single domain, reproducible spread: max |df| = %.3e, max |dx| = %.3e" % (err_f, worst))
+    if seam:
+        assert err_f <= 1e-12 and worst <= 1e-11, (err_f, worst)
+    else:
+        assert err_f == 0.0 and worst == 0.0, (err_f, worst)
+    assert sum(r["stats"]["cells_new"] + r["stats"]["cells_dropped"] for r in res) > 0
+
+
 @pytest.mark.parametrize("world,rep,padded", [(2, False, False), (3, False, False), (4, False, False), (2, True, False), (2, True, True)])
 def test_slabs_match_single_domain(tmp_path, gpu, world, rep, padded):
-    """rep: vertex-vertex and boundary-particle repulsion on (cell records then carry force_repulsion);
-    padded: the slabs (not the single-domain reference run) use the padded x-plane stride"""
+    """the default (atomic) spread.  rep: vertex-vertex and boundary-particle repulsion on (cell records then carry
+    force_repulsion); padded: the slabs (not the single-domain reference run) use the padded x-plane stride"""
     nxg = 192 if world == 4 else NXG          # a slab that carries cells is at least 40 planes wide
     res = _spawn(world, tmp_path, dict(rep=rep, padded=padded, nxg=nxg), salt=2 * rep + padded)
     ref, mask = _build(0, 1, rep, nxg=nxg)
@@ -140,7 +208,8 @@ def test_slabs_match_single_domain(tmp_path, gpu, world, rep, padded):
     err_f = np.abs(f_two - f_ref)[fluid].max()
     # both runs add the spread forces with fp64 atomics in whatever order the hardware takes them, so two runs of the SAME
     # configuration already differ in the last bits and drift apart over the 250 steps: seen 0.3e-12 ... 1.2e-12 from run to run
-    # (populations are O(0.1); north_star asks for 1e-6)
+    # (populations are O(0.1); north_star asks for 1e-6).  The comparison without that noise is
+    # test_slabs_equal_single_domain_bit_for_bit above (reproducible spread: exact)
     assert err_f <= 5e-12, err_f
     allpos = ref.cells.positions
     nrbc = len(CELLS) * 642
@@ -310,6 +379,54 @@ def test_cell_reaching_the_wall_is_deleted_on_every_holder(tmp_path, gpu, mode):
     got = np.concatenate([r["pos"] for r in res]); cid = np.concatenate([r["cid"] for r in res]); vid = np.concatenate([r["vid"] for r in res])
     assert (cid == 0).all() and sorted(vid.tolist()) == list(range(642))
     assert np.abs(got - p_ref[0, vid]).max() <= 1e-9
+
+
+def test_cell_compacted_between_synchronisations_stays_deleted(tmp_path, gpu):
+    """the wall contact happens after the last velocity update (iteration 0; the next one is iteration 60) and
+    the host then looks at the cells (writeOutput: deleteIncompleteCells + counts, iteration 58), which compacts the gone cell
+    away on the rank that saw the wall -- the other holder's copy must not come back as a fresh complete cell at iteration 60"""
+    kw = dict(cells=WALL_CELLS, plts=[], force=(1e-5, 0.0, 0.0), del_mode="particle", k_p=60)
+    res = _spawn(2, tmp_path, dict(kw, push=(1, (0.0, 0.0, 0.1)), query_at=58), steps=100, salt=41)
+    assert sum(int(r["held"]) for r in res) == 1                           # no copy lingers or returns
+    assert 1 <= sum(int(r["deleted"]) for r in res) <= 2                   # each holder counts its own copy once
+    cid = np.concatenate([r["cid"] for r in res]); vid = np.concatenate([r["vid"] for r in res])
+    assert (cid == 0).all() and sorted(vid.tolist()) == list(range(642))
+
+
+# <particleEnvelope> (core/hemoCell.cpp:139): cell 1 is given a held velocity of 0.25 lu per iteration along the pipe; velocities
+# are refreshed (and envelopes synchronised) every 60 iterations, so it travels 15 lu between two synchronisations and crosses the face
+# at x = 72 from 12 lu away
+FAST_CELLS = [((20.0, 16.5, 16.5), (90, 0, 0)), ((52.0, 16.5, 16.5), (90, 0, 0))]
+
+
+@pytest.mark.parametrize("envelope,ok", [(None, False), (25, False), (36, True)])
+def test_particle_envelope_knob_and_device_check(tmp_path, gpu, envelope, ok):
+    """the default (4 lu) and <particleEnvelope> 25 (25 - 15.6 = 9.4 lu for an RBC) are too small for 15 lu per velocity update:
+    the copy reaches the neighbour with particles already on its side, the merge kernel counts them and hc_iterate fails with
+    the envelope named; <particleEnvelope> 36 (20.4 lu, clamped to what a 72-plane slab supports) carries the same run, and
+    the result is the single domain's"""
+    kw = dict(cells=FAST_CELLS, plts=[], force=(1e-5, 0.0, 0.0), k_p=60, envelope=envelope)
+    push = (1, (0.25, 0.0, 0.0))
+    steps = 70
+    res = _spawn(2, tmp_path, dict(kw, push=push, expect_error=not ok), steps=steps, salt=51 + (envelope or 0))
+    share = [float(r["envelope"][0]) for r in res]
+    assert share[0] == share[1] and abs(share[0] - {None: 4.0, 25: 25 - 15.64, 36: 36 - 15.64}[envelope]) < 0.1, share
+    if not ok:
+        errs = [str(r["error"]) for r in res]
+        assert any("particle envelope too small" in e for e in errs), errs
+        assert sum(int(r["envelope"][1]) for r in res) > 0
+        return
+    assert all(str(r["error"]) == "" and int(r["envelope"][1]) == 0 for r in res)
+    ref, mask = _build(0, 1, **kw)
+    _run(ref, steps, push)
+    p_ref = ref.cells.positions.reshape(2, -1, 3)
+    seen = np.zeros((2, 642), dtype=int)
+    for r in res:
+        d = r["pos"] - p_ref[r["cid"], r["vid"]]
+        assert np.abs(d).max() <= 1e-10
+        np.add.at(seen, (r["cid"], r["vid"]), 1)
+    assert (seen == 1).all()
+    assert p_ref[1, :, 0].max() > 73.0                                                  # it did cross the face at x = 72
 
 
 def test_slab_schedule_over_rccl_matches_hc_iterate(gpu):

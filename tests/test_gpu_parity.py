@@ -277,6 +277,72 @@ def test_ibm_oversized_cells_take_the_fallback_paths(orc, gpu, scale, which):
     Lo.destroy(); Lg.destroy()
 
 
+def test_reproducible_spread(orc, gpu):
+    """hc_set_reproducible_spread (SURVEY section 7 hard parts: a deterministic, gather-based spread for parity runs).  The
+    reference adds particle by particle in storage order (core/hemoCellParticleField.cpp:841-863), so its runs repeat; the gather
+    form here sums every node's contributions in (type, cell id, vertex id) order: (1) the spread field equals the oracle's to
+    rounding of the sums (the oracle adds to the body force first, the kernels to zero), (2) two runs of one input give the
+    same bits, cells near a wall, across the periodic seam, RBC and PLT, with the side stream in use, (3) a cell stored in a
+    different slot gives the same bits (the order is by cell id, not by slot)"""
+    lib = gpu.capi.lib()
+    nx, ny, nz = 48, 34, 34
+    mask, R = gpu.pipe_mask(nx, ny, nz)
+    cells = [(0, (10.0, 16.5, 16.5), (90, 0, 0), 5), (0, (30.0, 16.0, 17.0), (70, 30, 10), 2), (0, (46.5, 17.0, 16.0), (90, 0, 30), 9),
+             (1, (20.0, 12.0, 20.0), (10, 20, 30), 4), (1, (24.0, 14.0, 12.5), (0, 0, 0), 1)]
+
+    def run(order, steps, reproducible):
+        gpu.check(lib.hc_set_reproducible_spread(1 if reproducible else 0))
+        P = gpu.base_parameters()
+        L = gpu.Lattice(nx, ny, nz, (1, 0, 0), 1.0 / P.tau); L.defineBounceBack(mask); L.latticeEquilibrium(); L.setExternalVector((3e-5, 0, 0))
+        h = gpu.HemoCell(L, P); cf = h.cellfields
+        cf.addCellType(gpu.CellType.rbc(P), 4); cf.addCellType(gpu.CellType.plt(P), 4)
+        h.setParticleVelocityUpdateTimeScaleSeparation(2); h.deletion_check_every = 10 ** 6
+        for k in order:
+            t, c, a, cid = cells[k]
+            assert cf.addCell(t, c, a, cell_id=cid)
+        cf.applyConstitutiveModel(0, True)
+        h.iterate(steps)
+        ids = cf.cell_ids()
+        pos = cf.positions
+        per_cell = {}
+        off = 0
+        for t, nvt in ((0, 642), (1, 66)):
+            n = cf.type_range(t)[1]
+            for c in range(n):
+                per_cell[(t, int(ids[sum(cf.type_range(u)[1] for u in range(t)) + c]))] = pos[off + c * nvt: off + (c + 1) * nvt].copy()
+            off += n * nvt
+        f = L.populations().copy()
+        L.destroy()
+        return f, per_cell
+
+    try:
+        f1, p1 = run([0, 1, 2, 3, 4], 80, True)
+        f2, p2 = run([0, 1, 2, 3, 4], 80, True)
+        assert np.array_equal(f1, f2) and all(np.array_equal(p1[k], p2[k]) for k in p1)          # (2)
+        f3, p3 = run([2, 0, 1, 4, 3], 80, True)                                                   # other slots, same ids
+        assert np.array_equal(f1, f3) and all(np.array_equal(p1[k], p3[k]) for k in p1)          # (3)
+        fa, pa = run([0, 1, 2, 3, 4], 80, False)                                                  # the atomic kernels: same physics
+        assert np.abs(fa - f1).max() <= 1e-12 and max(np.abs(pa[k] - p1[k]).max() for k in p1) <= 1e-10
+        # (1) one spread against the oracle
+        gpu.check(lib.hc_set_reproducible_spread(1))
+        Po, Lo, Lg, So, hg = _sim_pair(orc, gpu, nx, ny, nz, (1, 0, 0), mask, plt=True)
+        assert _add_both(orc, So, hg, 0, (46.5, 14.2, 15.1), (90, 0, 0)) and _add_both(orc, So, hg, 0, (18.0, 14.5, 9.6), (90, 20, 0))
+        assert _add_both(orc, So, hg, 1, (24.0, 14.0, 12.5), (0, 0, 0))
+        cf = hg.cellfields
+        pos_o, _, _ = _oracle_state(orc, So)
+        pos = pos_o + 0.03 * np.random.default_rng(3).standard_normal(pos_o.shape)
+        orc.orc_sim_set(So, 0, O.dptr(pos)); cf.positions = pos
+        orc.orc_sim_mechanics(So, 1)
+        _, _, f_o = _oracle_state(orc, So)
+        cf.forces = f_o                                        # the same vertex forces on both sides (the platelet law differs in its atan2 by an ulp)
+        Lo.set_force_uniform((0.0, 0.0, 0.0)); Lg.setExternalVector((0.0, 0.0, 0.0))
+        orc.orc_sim_spread(So); cf.spreadParticleForce(True)
+        assert np.array_equal(Lg.ibm_force(), Lo.force)      # zero body force: the same sums in the same order -> the same bits
+        Lo.destroy(); Lg.destroy()
+    finally:
+        gpu.check(lib.hc_set_reproducible_spread(0))
+
+
 @pytest.mark.parametrize("case", ["pipe_rbc", "pipe_rbc_plt_cadence", "box_periodic", "pipe_rbc_plt_cadence_beside", "box_kolmogorov"])
 def test_iterate_trajectories_vs_oracle(orc, gpu, case):
     """HemoCell::iterate for N steps: fluid populations and vertex positions within 1e-6 relative of the
@@ -946,11 +1012,22 @@ def test_particle_records_in_the_reference_layout(gpu):
     a, b = again[key(again)], back[key(back)]
     for name in cf.SV_DTYPE.names:
         assert np.array_equal(a[name], b[name]), name
-    # an incomplete cell is refused, as the reference would delete it before any mechanics
-    with pytest.raises(gpu.capi.HcError, match="incomplete"):
-        cf.set_records(back[:-1])
-    h.iterate(5)
+    # records of an incomplete cell (what removeParticles(1) leaves behind and a checkpoint may hold): the cell
+    # arrives incomplete, the records go out again as they came in, and deleteIncompleteCells removes it -- the reference's load
+    # path (core/hemoCellFields.cpp:272-274)
+    short = back[key(back)][:-3]                              # the platelet (last type) loses three particles
+    cf.set_records(short[rng.permutation(len(short))])
+    assert cf.counts()[:2] == (2 * 642 + 66, 3)               # slots are kept ...
+    assert cf.deletion_counts()[2:] == (1, 3)                 # ... one cell incomplete, three particles missing
+    out = cf.records()
+    assert len(out) == len(short)
+    for name in cf.SV_DTYPE.names:
+        assert np.array_equal(out[key(out)][name], short[name]), name
+    h.iterate(5)                                              # an incomplete cell takes no part in the mechanics and breaks nothing
     assert np.isfinite(cf.positions).all()
+    assert cf.deleteIncompleteCells() == 1 and cf.counts()[:2] == (2 * 642, 2)
+    with pytest.raises(gpu.capi.HcError, match="duplicate"):  # what is still refused: two records of one particle
+        cf.set_records(np.concatenate([back, back[:1]]))
     L.destroy()
 
 

@@ -318,7 +318,9 @@ def main():
     # or per unit of pipe (weak scaling); tests compare the N-slab figures with the 1-slab ones
     u_stats = runner.fluid_stats(0); rho_stats = runner.fluid_stats(2); v_stats = runner.vertex_stats(1)
     diagnostics = {"fluid_speed_max": u_stats[1], "fluid_speed_mean": u_stats[2], "fluid_nodes": u_stats[3],
-                   "mass": rho_stats[2] * rho_stats[3], "density_min": rho_stats[0], "density_max": rho_stats[1],
+                   # hcl_fluid_stats(2) reduces rhoBar = rho - 1 (the stored populations are f_i - t_i) over ALL nodes: its sum is the conserved
+                   # mass minus the node count
+                   "mass_minus_nodes": rho_stats[2] * rho_stats[3], "all_nodes": rho_stats[3], "rho_bar_min": rho_stats[0], "rho_bar_max": rho_stats[1],
                    "vertex_speed_max": v_stats[1], "vertex_speed_mean": v_stats[2], "owned_vertices": v_stats[3]}
 
     ms, n = C.c_double(), C.c_long()

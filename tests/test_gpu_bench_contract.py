@@ -103,7 +103,9 @@ def test_bench_config3_strong_scaling_four_slabs_equal_one(gpu):
     assert "pltSimpleModel platelets per RBC: 0.07" in four["config"]["workload"]
     a, b = one["diagnostics"], four["diagnostics"]
     assert a["fluid_nodes"] == b["fluid_nodes"] and a["owned_vertices"] == b["owned_vertices"]
-    assert abs(a["mass"] - b["mass"]) <= 1e-12 * a["mass"]
-    for key in ("fluid_speed_max", "fluid_speed_mean", "vertex_speed_max", "vertex_speed_mean", "density_min", "density_max"):
+    assert a["all_nodes"] == b["all_nodes"] == 512 * 256 * 256
+    assert abs(a["mass_minus_nodes"] - b["mass_minus_nodes"]) <= 1e-12 * a["all_nodes"]      # total mass to 1e-12 relative (and conserved: the sum stays ~0)
+    assert abs(a["mass_minus_nodes"]) <= 1e-9 * a["all_nodes"]
+    for key in ("fluid_speed_max", "fluid_speed_mean", "vertex_speed_max", "vertex_speed_mean", "rho_bar_min", "rho_bar_max"):
         assert abs(a[key] - b[key]) <= 1e-9 * abs(a[key]) + 1e-18, (key, a[key], b[key])
     assert four["slab_schedule"]["records_sent_rank0"] > 0

@@ -915,8 +915,12 @@ inline void HemoCell::saveCheckPoint() {
   if (global.rank == 0) {
     std::ofstream x((dir + "/checkpoint.xml").c_str());
     x << "<?xml version=\"1.0\" ?>\n<Checkpoint>\n<General><Iteration>" << iter << "</Iteration><OutDirectory>" << outDir << "/</OutDirectory></General>\n";
-    std::ifstream cfgin(configFile.c_str()); string line; bool first = true;
-    while (std::getline(cfgin, line)) { if (first && line.find("<?xml") != string::npos) { first = false; continue; } x << line << "\n"; }
+    // the <hemocell> element of the configuration this run was started with -- which is itself a checkpoint.xml when the
+    // run was resumed: only the element is copied, not the <Checkpoint> wrapper around it
+    std::ifstream cfgin(configFile.c_str()); std::stringstream whole; whole << cfgin.rdbuf();
+    const string text = whole.str();
+    const size_t a = text.find("<hemocell"), b = text.rfind("</hemocell>");
+    if (a != string::npos && b != string::npos && b > a) x << text.substr(a, b - a) << "</hemocell>\n";
     x << "</Checkpoint>\n";
   }
   hlog << "(HemoCell) (saveCheckPoint) saved iteration " << iter << " to " << dir << endl;

@@ -735,6 +735,18 @@ int hcl_face_velocity_pack(hc_lattice *L, int side, double *dev_buf) {
   return HC_OK;
 }
 
+// inspection: the same plane of velocities on the host, [3][ny*nz] (tests; the message itself never touches the host)
+int hcl_download_face_velocity(hc_lattice *L, int side, double *host_u) {
+  HC_REQUIRE(L && host_u && (side == 0 || side == 1), "hcl_download_face_velocity: bad arguments");
+  double *d = nullptr;
+  HC_HIP(hipMalloc((void **)&d, 3 * L->plane * sizeof(double)));
+  int rc = hcl_face_velocity_pack(L, side, d);
+  if (rc == HC_OK && hipMemcpyAsync(host_u, d, 3 * L->plane * sizeof(double), hipMemcpyDeviceToHost, hc::stream()) != hipSuccess) { hc::set_error("hcl_download_face_velocity: copy failed"); rc = HC_ERR_HIP; }
+  if (rc == HC_OK && hipStreamSynchronize(hc::stream()) != hipSuccess) { hc::set_error("hcl_download_face_velocity: synchronise failed"); rc = HC_ERR_HIP; }
+  hipFree(d);
+  return rc;
+}
+
 int hcp_interpolate_cells(hc_cells *C, int type, const int *slots, int n) {
   HC_REQUIRE(C && type >= 0 && type < C->ntypes && n >= 0, "hcp_interpolate_cells: bad arguments");
   if (n == 0) return HC_OK;

@@ -187,6 +187,7 @@ int hcl_halo_pack_next(hc_lattice *L, int side, int width, double *dev_buf);
  * their owner on the post-stream state and packed as [3][ny*nz] doubles (device pointer) for the neighbour whose first halo
  * plane it is -- 3 planes instead of the 19 population planes of a width-2 halo.  hc_iterate exchanges them itself. */
 int hcl_face_velocity_pack(hc_lattice *L, int side, double *dev_buf);
+int hcl_download_face_velocity(hc_lattice *L, int side, double *host_u /*[3][ny*nz]*/);   /* the same plane on the host, for inspection */
 int hcl_dims(const hc_lattice *L, int dims[3]);
 /* counts[0] = bulk nodes of this slab, [1] = fluid nodes (GuoExternalForceBGKdynamics), [2] = nodes the collide kernel
  * loads and stores (everything but solid nodes without a fluid neighbour, which full-way bounce-back leaves inert) */

@@ -109,3 +109,26 @@ def test_bench_config3_strong_scaling_four_slabs_equal_one(gpu):
     for key in ("fluid_speed_max", "fluid_speed_mean", "vertex_speed_max", "vertex_speed_mean", "rho_bar_min", "rho_bar_max"):
         assert abs(a[key] - b[key]) <= 1e-9 * abs(a[key]) + 1e-18, (key, a[key], b[key])
     assert four["slab_schedule"]["records_sent_rank0"] > 0
+
+
+def test_bench_64_plane_slabs_five_ranks_equal_one(gpu):
+    """the slab thickness BASELINE config 3 gives each of 8 GPUs -- 64 planes of 256 x 256 -- with real neighbours on both faces:
+    five ranks of 64 planes (the box allows five rank processes beside this one) against the one-slab run of the same 320 x 256 x
+    256 pipe with RBC and PLT: same cells, owned vertices, mass and velocity statistics after 15 iterations"""
+    common = ["--ny", "256", "--nz", "256", "--plt-ratio", "0.07", "--steps", "10", "--warmup", "5", "--copy-reps", "2"]
+    one = _run(["--nx", "320", "--no-cpu-baseline"] + common)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HEMOCELL_TRANSPORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "5", "--nx", "64", "--transport", "tcp"] + common, cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    five = json.loads(lines[0])
+    assert five["n_gpus"] == 5 and one["config"]["lattice"] == five["config"]["lattice"] == [320, 256, 256]
+    assert one["config"]["cells"] == five["config"]["cells"] > 2000 and one["config"]["vertices"] == five["config"]["vertices"]
+    a, b = one["diagnostics"], five["diagnostics"]
+    assert a["fluid_nodes"] == b["fluid_nodes"] and a["owned_vertices"] == b["owned_vertices"] and a["all_nodes"] == b["all_nodes"]
+    assert abs(a["mass_minus_nodes"] - b["mass_minus_nodes"]) <= 1e-12 * a["all_nodes"]
+    for key in ("fluid_speed_max", "fluid_speed_mean", "vertex_speed_max", "vertex_speed_mean", "rho_bar_min", "rho_bar_max"):
+        assert abs(a[key] - b[key]) <= 1e-9 * abs(a[key]) + 1e-18, (key, a[key], b[key])
+    assert five["slab_schedule"]["records_sent_rank0"] > 100          # at 64 planes most cells of a slab sit within the envelope of a face

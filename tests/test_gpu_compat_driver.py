@@ -249,7 +249,7 @@ def test_every_fluid_output_variable(tmp_path, gpu):
             assert np.abs(two[rk] - one[:, :, 48 * rk:48 * rk + 50]).max() <= 2e-5 * scale, (name, rk)
 
 
-def _launch_ranks(exe, args, cwd, world, salt=0):
+def _launch_ranks(exe, args, cwd, world, salt=0, expect_ok=True):
     """a driver binary started as `world` processes the way mpirun would start them (rank and size in the environment); the
     ranks share the one GPU of the test box, so the data plane is the host-staged one"""
     port = str(30000 + (os.getpid() * 7 + salt * 131) % 20000)
@@ -261,6 +261,8 @@ def _launch_ranks(exe, args, cwd, world, salt=0):
             env.pop(k, None)
         procs.append(subprocess.Popen([exe] + args, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=900)[0] for p in procs]
+    if not expect_ok:
+        return outs, [p.returncode for p in procs]
     assert [p.returncode for p in procs] == [0] * world, "".join(o[-1500:] for o in outs)
     return outs
 
@@ -318,6 +320,12 @@ def test_two_rank_checkpoint_and_resume(tmp_path, gpu):
     stat_again = [l for l in again[0].splitlines() if l.startswith("STAT")]
     assert stat_again == stat_full[2:], (stat_again, stat_full)
     assert "resumed at iteration 200" in open(os.path.join(case, "tmp_pipe", "log", "logfile.0")).read()
+    # ranks that hold dumps of different iterations are refused: rank 1 gets its previous dump back
+    assert os.path.exists(os.path.join(ck, "checkpoint.1.bin.old"))
+    shutil.copy(os.path.join(ck, "checkpoint.1.bin.old"), os.path.join(ck, "checkpoint.1.bin"))
+    outs, rcs = _launch_ranks(exe, ["tmp_pipe/checkpoint/checkpoint.xml"], case, 2, salt=3, expect_ok=False)
+    assert rcs == [1, 1], (rcs, outs[0][-800:], outs[1][-800:])
+    assert "different iterations" in outs[0]
 
 
 def test_moving_wall_couette_vs_oracle(orc, gpu):

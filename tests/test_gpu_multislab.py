@@ -279,6 +279,26 @@ def _oracle_run(orc, nxg, steps, cells=CELLS, plts=PLTS, force=FORCE, k_p=K_P, k
     return Lo.f.copy(), pos, alive.astype(bool), mask
 
 
+def test_slabs_with_the_reproducible_spread_match_the_oracle(tmp_path, gpu, orc, reproducible_spread):
+    """the same comparison with the gather-form spread: what is left is the oracle adding each contribution to the body force
+    where the kernels add their sum to it, and the platelet law's atan2"""
+    steps = 120
+    res = _spawn(3, tmp_path, dict(), steps=steps, salt=27)
+    f_o, p_o, alive, mask = _oracle_run(orc, NXG, steps)
+    f_s = np.concatenate([r["f"].reshape(NXG // 3, NY * NZ, 19) for r in res], axis=0)
+    fluid = (mask.reshape(NXG, NY * NZ) == 0)
+    err_f = np.abs(f_s - f_o.reshape(NXG, NY * NZ, 19))[fluid].max()
+    nrbc = len(CELLS) * 642
+    worst = 0.0
+    for key, p_ref in ((("cid", "vid", "pos"), p_o[:nrbc].reshape(len(CELLS), -1, 3)), (("pcid", "pvid", "ppos"), p_o[nrbc:].reshape(len(PLTS), -1, 3))):
+        for r in res:
+            d = r[key[2]] - p_ref[r[key[0]], r[key[1]]]
+            d[:, 0] = (d[:, 0] + NXG / 2) % NXG - NXG / 2
+            worst = max(worst, np.abs(d).max() if len(d) else 0.0)
+    print("3 slabs, reproducible spread, vs the oracle: max |df| = %.3e, max |dx| = %.3e" % (err_f, worst))
+    assert err_f <= 1e-11 and worst <= 1e-9, (err_f, worst)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_slabs_match_the_oracle(tmp_path, gpu, orc, world):
     """row a12 against the ORACLE, not against the HIP single domain: the reference's result does not depend on the number
@@ -427,6 +447,34 @@ def test_particle_envelope_knob_and_device_check(tmp_path, gpu, envelope, ok):
         np.add.at(seen, (r["cid"], r["vid"]), 1)
     assert (seen == 1).all()
     assert p_ref[1, :, 0].max() > 73.0                                                  # it did cross the face at x = 72
+
+
+def test_envelope_argument_checks(gpu):
+    """hcp_set_envelope: before the first cell, after the cell types, positive; on one GPU the value is kept as it is"""
+    P = gpu.base_parameters()
+    L = gpu.Lattice(48, NY, NZ, (1, 0, 0), 1.0 / P.tau)
+    mask, _ = gpu.pipe_mask(48, NY, NZ)
+    L.defineBounceBack(mask); L.latticeEquilibrium()
+    h = gpu.HemoCell(L, P); cf = h.cellfields
+    lib = gpu.capi.lib()
+    import ctypes as C
+    used = C.c_double()
+    with pytest.raises(gpu.capi.HcError, match="cell types first"):
+        gpu.check(lib.hcp_set_envelope(cf.ptr, 25.0, C.byref(used)))
+    cf.addCellType(gpu.CellType.rbc(P), 1)
+    with pytest.raises(gpu.capi.HcError, match="positive"):
+        gpu.check(lib.hcp_set_envelope(cf.ptr, -1.0, C.byref(used)))
+    gpu.check(lib.hcp_set_envelope(cf.ptr, 25.0, C.byref(used)))
+    assert abs(used.value - (25.0 - 15.64)) < 0.1                    # envelope minus the RBC's diameter at dx = 0.5 um
+    gpu.check(lib.hcp_set_envelope(cf.ptr, 10.0, C.byref(used)))
+    assert used.value == 2.0                                          # never below what the IBM stencil needs
+    late = C.c_long(-1)
+    gpu.check(lib.hcp_envelope(cf.ptr, C.byref(used), C.byref(late)))
+    assert used.value == 2.0 and late.value == 0
+    assert cf.addCell(0, (24.0, 16.5, 16.5), (90, 0, 0))
+    with pytest.raises(gpu.capi.HcError, match="before the first cell"):
+        gpu.check(lib.hcp_set_envelope(cf.ptr, 25.0, C.byref(used)))
+    L.destroy()
 
 
 def test_slab_schedule_over_rccl_matches_hc_iterate(gpu):

@@ -277,6 +277,43 @@ def test_ibm_oversized_cells_take_the_fallback_paths(orc, gpu, scale, which):
     Lo.destroy(); Lg.destroy()
 
 
+def test_face_plane_velocities_vs_oracle(orc, gpu):
+    """the message of a velocity update between slabs (hcl_face_velocity_pack): u = j/rho + F/2 on the two face planes, evaluated
+    by their owner -- against Cell::computeVelocity of the oracle (orc_node_rho_u) on the same planes after coupled iterations,
+    with a cell whose force field reaches plane 0 across the periodic seam"""
+    nx, ny, nz = 40, 30, 30
+    mask, R = gpu.pipe_mask(nx, ny, nz)
+    Po, Lo, Lg, So, hg = _sim_pair(orc, gpu, nx, ny, nz, (1, 0, 0), mask, k_m=2, k_p=1)
+    assert _add_both(orc, So, hg, 0, (38.5, 14.2, 15.1), (90, 0, 0)) and _add_both(orc, So, hg, 0, (18.0, 14.5, 12.0), (90, 20, 0))
+    F = (2e-5, 0.0, 0.0)
+    Lo.set_force_uniform(F); Lg.setExternalVector(F)
+    So.contents.body_force[0], So.contents.body_force[1], So.contents.body_force[2] = F
+    orc.orc_sim_mechanics(So, 1); hg.cellfields.applyConstitutiveModel(0, True)
+    for _ in range(7):
+        orc.orc_sim_iterate(So)
+    hg.iterate(7)
+    # one more iteration up to the point where the reference interpolates: spread, collide-stream (the force field still holds
+    # what the collide used, core/hemoCell.cpp:313-329)
+    orc.orc_sim_spread(So); orc.orc_collide_stream(Lo.ptr)
+    hg.cellfields.spreadParticleForce(True); Lg.collideAndStream(1)
+    lib = gpu.capi.lib()
+    scale = 0.0
+    for side, x in ((0, 0), (1, nx - 1)):
+        u_g = np.zeros((3, ny * nz))
+        gpu.check(lib.hcl_download_face_velocity(Lg.ptr, side, gpu.dptr(u_g)))
+        u_o = np.zeros((ny * nz, 3))
+        for k in range(ny * nz):
+            r_, u_ = C.c_double(), np.zeros(3)
+            orc.orc_node_rho_u(Lo.ptr, x * ny * nz + k, C.byref(r_), gpu.dptr(u_))
+            u_o[k] = u_
+        fluid = mask.reshape(nx, ny * nz)[x] == 0
+        scale = max(scale, np.abs(u_o[fluid]).max())
+        assert np.abs(u_g.T[fluid] - u_o[fluid]).max() <= 1e-13 * np.abs(u_o[fluid]).max(), side
+        assert (u_g.T[~fluid] == 0).all()                     # stencils admit fluid nodes only
+    assert scale > 1e-6                                        # the flow is up
+    Lo.destroy(); Lg.destroy()
+
+
 def test_reproducible_spread(orc, gpu):
     """hc_set_reproducible_spread (SURVEY section 7 hard parts: a deterministic, gather-based spread for parity runs).  The
     reference adds particle by particle in storage order (core/hemoCellParticleField.cpp:841-863), so its runs repeat; the gather

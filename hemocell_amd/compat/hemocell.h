@@ -485,6 +485,13 @@ class HemoCell {
     if (global.world == 1) hc_check(hc_init(0), "hc_init");
     cfg = new Config(configFileName);
     configFile = configFileName;
+    {   // the <hemocell> element as text, for checkpoint.xml (core/hemoCellFields.cpp:283-319); kept from now because a resumed
+        // run's configuration IS the checkpoint.xml that saveCheckPoint rotates away before it writes the new one
+      std::ifstream cfgin(configFileName); std::stringstream whole; whole << cfgin.rdbuf();
+      const string text = whole.str();
+      const size_t a = text.find("<hemocell"), b = text.rfind("</hemocell>");
+      if (a != string::npos && b != string::npos && b > a) configElement = text.substr(a, b - a) + "</hemocell>\n";
+    }
     try { global.cellsDeletedInfo = (*cfg)["verbose"]["cellsDeletedInfo"].read<int>() != 0; } catch (std::invalid_argument &) {}   // config/config.cpp:180
     if (global.rank != 0) hlog_instance().to_stdout = false;   // the log is rank 0's (config/logfile.h)
     loadDirectories(true);
@@ -659,7 +666,7 @@ class HemoCell {
   HemoCellFields *cellfields = nullptr;
   unsigned int iter = 0;
   void *preInlet = nullptr;
-  string outDir, configFile;
+  string outDir, configFile, configElement;
   vector<int> fluidOutputs;
 };
 
@@ -915,12 +922,9 @@ inline void HemoCell::saveCheckPoint() {
   if (global.rank == 0) {
     std::ofstream x((dir + "/checkpoint.xml").c_str());
     x << "<?xml version=\"1.0\" ?>\n<Checkpoint>\n<General><Iteration>" << iter << "</Iteration><OutDirectory>" << outDir << "/</OutDirectory></General>\n";
-    // the <hemocell> element of the configuration this run was started with -- which is itself a checkpoint.xml when the
-    // run was resumed: only the element is copied, not the <Checkpoint> wrapper around it
-    std::ifstream cfgin(configFile.c_str()); std::stringstream whole; whole << cfgin.rdbuf();
-    const string text = whole.str();
-    const size_t a = text.find("<hemocell"), b = text.rfind("</hemocell>");
-    if (a != string::npos && b != string::npos && b > a) x << text.substr(a, b - a) << "</hemocell>\n";
+    // the <hemocell> element of the configuration this run was started with (read at start-up): only the element, not the
+    // <Checkpoint> wrapper a resumed run's configuration has around it
+    x << configElement;
     x << "</Checkpoint>\n";
   }
   hlog << "(HemoCell) (saveCheckPoint) saved iteration " << iter << " to " << dir << endl;

@@ -119,7 +119,8 @@ int hc_init(int device) {
     // queue).  Streams of different priority never share one, so the side stream is created with the highest priority.
     int lo = 0, hi = 0;
     HC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HC_HIP(hipStreamCreateWithPriority(&hc::g_side, hipStreamNonBlocking, hi));
+    const char *pe = std::getenv("HEMOCELL_SIDE_PRIORITY");   // A/B: "low" = the side stream below the main stream instead of above it
+    HC_HIP(hipStreamCreateWithPriority(&hc::g_side, hipStreamNonBlocking, (pe && pe[0] == 'l') ? lo : hi));
     HC_HIP(hipStreamCreateWithPriority(&hc::g_comm, hipStreamNonBlocking, hi));
     HC_HIP(hipEventCreateWithFlags(&hc::g_fork_ev, hipEventDisableTiming));
     HC_HIP(hipEventCreateWithFlags(&hc::g_join_ev, hipEventDisableTiming));

@@ -150,7 +150,8 @@ int hcl_collide_stream(hc_lattice *L, int nsteps);
 int hcl_slab_refresh_halos(hc_lattice *L, int width);
 /* one collide-stream of this slab; halos must be current. part: 0 = all planes, 1 = interior planes
  * (those that do not read halo data), 2 = the two face planes; or 3 = planes 2..nx-3, 4 = the two planes next to each
- * face (what a width-2 halo message is packed from, so that it can travel while part 3 runs).
+ * face (what the node velocities of a face plane are evaluated from, hcl_face_velocity_pack, so that the messages of a velocity
+ * update can travel while part 3 runs).
  * hcl_step_end() flips the buffers. */
 int hcl_collide_stream_part(hc_lattice *L, int part);
 int hcl_step_end(hc_lattice *L);

@@ -380,6 +380,32 @@ def test_reproducible_spread(orc, gpu):
         gpu.check(lib.hc_set_reproducible_spread(0))
 
 
+@pytest.mark.parametrize("which", ["trajectories", "trajectories_beside", "wall_particle", "wall_cell", "repulsion", "boundary_repulsion", "oversized"])
+def test_parity_cases_again_with_the_reproducible_spread(orc, gpu, which):
+    """the gather-form spread behind the same oracle comparisons as the atomic kernels: coupled trajectories (also with the side
+    stream in use), particles removed at a wall in both deletion modes (removed particles have no entries), force_repulsion in the
+    spread sum, and a cell larger than the per-cell kernels' tile (the gather form has no tile)"""
+    lib = gpu.capi.lib()
+    gpu.check(lib.hc_set_reproducible_spread(1))
+    try:
+        if which == "trajectories":
+            test_iterate_trajectories_vs_oracle(orc, gpu, "pipe_rbc_plt_cadence")
+        elif which == "trajectories_beside":
+            test_iterate_trajectories_vs_oracle(orc, gpu, "pipe_rbc_plt_cadence_beside")
+        elif which == "wall_particle":
+            test_cell_removed_when_it_reaches_the_wall(orc, gpu, "particle")
+        elif which == "wall_cell":
+            test_cell_removed_when_it_reaches_the_wall(orc, gpu, "cell")
+        elif which == "repulsion":
+            test_repulsion_vs_oracle(orc, gpu)
+        elif which == "boundary_repulsion":
+            test_boundary_particle_repulsion_vs_oracle(orc, gpu)
+        else:
+            test_ibm_oversized_cells_take_the_fallback_paths(orc, gpu, 1.5, "tile")
+    finally:
+        gpu.check(lib.hc_set_reproducible_spread(0))
+
+
 @pytest.mark.parametrize("case", ["pipe_rbc", "pipe_rbc_plt_cadence", "box_periodic", "pipe_rbc_plt_cadence_beside", "box_kolmogorov"])
 def test_iterate_trajectories_vs_oracle(orc, gpu, case):
     """HemoCell::iterate for N steps: fluid populations and vertex positions within 1e-6 relative of the

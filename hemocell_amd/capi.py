@@ -92,6 +92,10 @@ SIGNATURES = {
     "hcl_halo_unpack": (C.c_int, [VP, C.c_int, C.c_int, VP]),
     "hcl_halo_pack_next": (C.c_int, [VP, C.c_int, C.c_int, VP]),
     "hcl_face_velocity_pack": (C.c_int, [VP, C.c_int, VP]),
+    "hcl_face_velocity_pack_both": (C.c_int, [VP, VP, VP]),
+    "hcl_halo_pack_both": (C.c_int, [VP, VP, VP, C.c_int]),
+    "hcl_halo_unpack_both": (C.c_int, [VP, VP, VP]),
+    "hcl_zero_force_halos": (C.c_int, [VP]),
     "hcl_download_face_velocity": (C.c_int, [VP, C.c_int, c_double_p]),
     "hcl_dims": (C.c_int, [VP, c_int_p]),
     "hcl_mlups_bytes_per_node": (C.c_double, [VP]),

@@ -149,9 +149,11 @@ __device__ __forceinline__ void node_velocity(const LatView &v, const PopView &p
 }
 
 // node velocities of one face plane of a slab (lx = 0 or nx - 1), for the neighbour whose first halo plane it is
-__global__ __launch_bounds__(256) void face_velocity_kernel(LatView v, PopView pv, int lx, double *out) {
+__global__ __launch_bounds__(256) void face_velocity_kernel(LatView v, PopView pv, int lx0, double *out0, int lx1, double *out1) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= v.ny_nz) return;
+  const int lx = blockIdx.y ? lx1 : lx0;           // blockIdx.y: which of the (up to two) planes of the launch
+  double *out = blockIdx.y ? out1 : out0;
   const int ly = k / v.nz, lz = k - ly * v.nz;
   const long node = (long)(lx + HALO) * v.plane + (long)ly * v.nz + lz;
   double u[3] = {0.0, 0.0, 0.0};
@@ -730,7 +732,19 @@ int hcl_face_velocity_pack(hc_lattice *L, int side, double *dev_buf) {
   LatView v = make_view(L);
   v.halo_u[0] = v.halo_u[1] = nullptr;   // own planes only: nothing here reads a halo velocity
   PopView pv{L->f[L->cur], L->force[(L->fcur + 2) % 3], L->body[0], L->body[1], L->body[2], (long)L->qstride, L->regions};
-  hipLaunchKernelGGL(face_velocity_kernel, dim3((unsigned)((L->plane + 255) / 256)), dim3(256), 0, hc::stream(), v, pv, side == 0 ? 0 : L->nx - 1, dev_buf);
+  hipLaunchKernelGGL(face_velocity_kernel, dim3((unsigned)((L->plane + 255) / 256), 1, 1), dim3(256), 0, hc::stream(), v, pv, side == 0 ? 0 : L->nx - 1, dev_buf, 0, (double *)nullptr);
+  HC_HIP(hipGetLastError());
+  return HC_OK;
+}
+// both face planes in one launch (either buffer may be null)
+int hcl_face_velocity_pack_both(hc_lattice *L, double *dev_lo, double *dev_hi) {
+  HC_REQUIRE(L, "hcl_face_velocity_pack_both: null lattice");
+  if (!dev_lo && !dev_hi) return HC_OK;
+  if (!dev_lo || !dev_hi) return hcl_face_velocity_pack(L, dev_lo ? 0 : 1, dev_lo ? dev_lo : dev_hi);
+  LatView v = make_view(L);
+  v.halo_u[0] = v.halo_u[1] = nullptr;
+  PopView pv{L->f[L->cur], L->force[(L->fcur + 2) % 3], L->body[0], L->body[1], L->body[2], (long)L->qstride, L->regions};
+  hipLaunchKernelGGL(face_velocity_kernel, dim3((unsigned)((L->plane + 255) / 256), 2, 1), dim3(256), 0, hc::stream(), v, pv, 0, dev_lo, L->nx - 1, dev_hi);
   HC_HIP(hipGetLastError());
   return HC_OK;
 }

@@ -38,6 +38,7 @@ struct LatArgs {
   long npad;
   long qs;               // population stride (npad + padding)
   int x_begin;
+  int x_split, x_jump;   // one launch over two ranges of planes (the planes next to the two faces of a slab): blockIdx.y >= x_split -> x += x_jump
   int wrap_x, per_y, per_z;
   double omega;
   double bx, by, bz;
@@ -178,7 +179,7 @@ template <bool REGIONS>
 __global__ __launch_bounds__(256) void collide_stream_kernel(LatArgs a) {
   // thread -> (y,z) through the active-span map of this plane: consecutive threads walk the spans of
   // consecutive rows, so every lane of every wave (except the last of a plane) has a live node
-  const int x = a.x_begin + blockIdx.y;
+  const int x = a.x_begin + (int)blockIdx.y + ((int)blockIdx.y >= a.x_split ? a.x_jump : 0);
   const int xp = x + HALO;
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int *cum = a.row_cum + (long)xp * (a.ny + 1);
@@ -393,6 +394,7 @@ __global__ __launch_bounds__(256) void fluid_stats_kernel(LatArgs a, int what, d
 struct HaloArgs {
   double *f;          // population buffer
   double *buf;        // contiguous staging
+  double *buf2; int n_first;   // entries e >= n_first belong to the second staging block (both faces in one launch)
   long npad; long xs; int plane;   // npad: population stride, xs: x-plane stride
   int n;              // (population, plane) entries
   int pop[HC_Q + 5];  // population of entry e
@@ -404,8 +406,8 @@ __global__ void halo_copy_kernel(HaloArgs h) {
   if (p >= h.plane) return;
   const int e = blockIdx.y;
   const long li = (long)h.pop[e] * h.npad + (long)h.xp[e] * h.xs + p;
-  const long bi = (long)e * h.plane + p;
-  if (h.to_buf) h.buf[bi] = h.f[li]; else h.f[li] = h.buf[bi];
+  double *b = e < h.n_first ? h.buf + (long)e * h.plane + p : h.buf2 + (long)(e - h.n_first) * h.plane + p;
+  if (h.to_buf) *b = h.f[li]; else h.f[li] = *b;
 }
 
 // clears the 2*HALO halo planes of the three IBM force components
@@ -422,6 +424,7 @@ LatArgs make_args(const hc_lattice *L) {
   a.fin = L->f[L->cur]; a.fout = L->f[1 - L->cur];
   const int fprev = (L->fcur + 2) % 3;
   a.Fin = L->force[L->fcur]; a.Fzero = L->force[fprev];
+  a.x_split = 0x7fffffff; a.x_jump = 0;
   a.mask = L->mask;
   a.nx = L->nx; a.ny = L->ny; a.nz = L->nz; a.plane = (int)L->plane; a.xs = (long)L->xs; a.npad = (long)L->npad; a.qs = (long)L->qstride;
   a.x_begin = 0;
@@ -513,12 +516,15 @@ int rebuild_wall_bricks(hc_lattice *L) {
   return HC_OK;
 }
 
-int launch_collide(hc_lattice *L, int x_begin, int nplanes) {
-  if (nplanes <= 0) return HC_OK;
+// planes [x_begin, x_begin + nplanes) and, in the same launch, [x2, x2 + n2) (n2 = 0: one range)
+int launch_collide(hc_lattice *L, int x_begin, int nplanes, int x2 = 0, int n2 = 0) {
+  if (nplanes + n2 <= 0) return HC_OK;
   LatArgs a = make_args(L);
   a.x_begin = x_begin;
-  if (L->regions.n) hipLaunchKernelGGL(collide_stream_kernel<true>, dim3((unsigned)((L->max_active + 255) / 256), (unsigned)nplanes, 1), dim3(256), 0, hc::stream(), a);
-  else hipLaunchKernelGGL(collide_stream_kernel<false>, dim3((unsigned)((L->max_active + 255) / 256), (unsigned)nplanes, 1), dim3(256), 0, hc::stream(), a);
+  if (n2 > 0) { a.x_split = nplanes; a.x_jump = x2 - (x_begin + nplanes); }
+  const unsigned ny = (unsigned)(nplanes + n2);
+  if (L->regions.n) hipLaunchKernelGGL(collide_stream_kernel<true>, dim3((unsigned)((L->max_active + 255) / 256), ny, 1), dim3(256), 0, hc::stream(), a);
+  else hipLaunchKernelGGL(collide_stream_kernel<false>, dim3((unsigned)((L->max_active + 255) / 256), ny, 1), dim3(256), 0, hc::stream(), a);
   HC_HIP(hipGetLastError());
   return HC_OK;
 }
@@ -715,23 +721,29 @@ int hcl_set_body_force_regions(hc_lattice *L, int n, const int *boxes, const dou
 
 int hcl_collide_stream_part(hc_lattice *L, int part) {
   HC_REQUIRE(L, "hcl_collide_stream_part: null lattice");
-  HC_REQUIRE(part >= 0 && part <= 4, "hcl_collide_stream_part: part must be 0..4");
-  HC_REQUIRE(part < 3 || L->nx >= 4, "hcl_collide_stream_part: parts 3 and 4 need a slab of at least 4 planes");
+  HC_REQUIRE(part >= 0 && part <= 6, "hcl_collide_stream_part: part must be 0..6");
+  HC_REQUIRE(part < 3 || L->nx >= 4, "hcl_collide_stream_part: parts 3, 4 and 6 need a slab of at least 4 planes");
   hc::ProfScope prof(hc::forked() ? hc::PK_COLLIDE_BESIDE : hc::PK_COLLIDE);
   int rc = HC_OK;
   if (part == 0) rc = launch_collide(L, 0, L->nx);
   else if (part == 1) rc = launch_collide(L, 1, L->nx - 2);
-  else if (part == 2) { rc = launch_collide(L, 0, 1); if (rc == HC_OK) rc = launch_collide(L, L->nx - 1, 1); }
+  else if (part == 2 || part == 5) rc = launch_collide(L, 0, 1, L->nx - 1, 1);       // both face planes in one launch
   else if (part == 3) rc = launch_collide(L, 2, L->nx - 4);
-  else { rc = launch_collide(L, 0, 2); if (rc == HC_OK) rc = launch_collide(L, L->nx - 2, 2); }
-  if (rc == HC_OK && L->n_slabs > 1 && (part == 0 || part == 2 || part == 4) && L->ibm) {
-    // the kernel zeroes the other-parity IBM force on the bulk planes; envelope copies of cells also
-    // spread onto the halo planes, which have to be cleared as well (one small launch)
-    hipLaunchKernelGGL(zero_force_halo_kernel, dim3((unsigned)((L->plane + 255) / 256), (unsigned)(2 * HALO * 3), 1), dim3(256), 0, hc::stream(),
-                       L->force[(L->fcur + 2) % 3], (long)L->npad, (long)L->xs, (int)L->plane, L->nx);
-    HC_HIP(hipGetLastError());
-  }
+  else rc = launch_collide(L, 0, 2, L->nx - 2, 2);                                  // the two planes next to each face in one launch
+  if (rc == HC_OK && (part == 0 || part == 2 || part == 4)) rc = hcl_zero_force_halos(L);
   return rc;
+}
+
+// The collide kernel zeroes the other-parity IBM force on the bulk planes; envelope copies of cells also spread onto the halo
+// planes, which have to be cleared as well (one small launch; before hcl_step_end of the same step).  Parts 0, 2 and 4 of
+// hcl_collide_stream_part do it themselves; after parts 5 / 6 (the slab schedule) the caller does, once its face message is away.
+int hcl_zero_force_halos(hc_lattice *L) {
+  HC_REQUIRE(L, "hcl_zero_force_halos: null lattice");
+  if (L->n_slabs <= 1 || !L->ibm) return HC_OK;
+  hipLaunchKernelGGL(zero_force_halo_kernel, dim3((unsigned)((L->plane + 255) / 256), (unsigned)(2 * HALO * 3), 1), dim3(256), 0, hc::stream(),
+                     L->force[(L->fcur + 2) % 3], (long)L->npad, (long)L->xs, (int)L->plane, L->nx);
+  HC_HIP(hipGetLastError());
+  return HC_OK;
 }
 
 int hcl_step_end(hc_lattice *L) {
@@ -865,7 +877,7 @@ static int halo_copy(hc_lattice *L, int side, int width, double *buf, int to_buf
   static const int cxm[5] = {1, 4, 5, 6, 7};        // c_x = -1
   static const int cxp[5] = {10, 13, 14, 15, 16};   // c_x = +1
   HaloArgs h;
-  h.f = L->f[next ? 1 - L->cur : L->cur]; h.buf = buf; h.npad = (long)L->qstride; h.xs = (long)L->xs; h.plane = (int)L->plane; h.to_buf = to_buf; h.n = 0;
+  h.f = L->f[next ? 1 - L->cur : L->cur]; h.buf = buf; h.buf2 = nullptr; h.n_first = 0x7fffffff; h.npad = (long)L->qstride; h.xs = (long)L->xs; h.plane = (int)L->plane; h.to_buf = to_buf; h.n = 0;
   // the populations that travel towards -x (cxm) leave through the low face and arrive in the low neighbour's high
   // halo; those towards +x (cxp) the other way round
   const int *moving = to_buf ? (side == 0 ? cxm : cxp) : (side == 0 ? cxp : cxm);
@@ -887,6 +899,28 @@ static int halo_copy(hc_lattice *L, int side, int width, double *buf, int to_buf
   HC_HIP(hipGetLastError());
   return HC_OK;
 }
+// the width-1 message of both faces in one launch (either buffer may be null: a slab at a non-periodic end of the domain)
+static int halo_copy_both(hc_lattice *L, double *buf_lo, double *buf_hi, int to_buf, int next) {
+  HC_REQUIRE(L, "hcl_halo: null pointer");
+  HC_REQUIRE(L->nx >= 2, "hcl_halo: slab thinner than the halo");
+  static const int cxm[5] = {1, 4, 5, 6, 7};        // c_x = -1
+  static const int cxp[5] = {10, 13, 14, 15, 16};   // c_x = +1
+  HaloArgs h;
+  h.f = L->f[next ? 1 - L->cur : L->cur]; h.npad = (long)L->qstride; h.xs = (long)L->xs; h.plane = (int)L->plane; h.to_buf = to_buf; h.n = 0;
+  h.buf = buf_lo; h.buf2 = buf_hi; h.n_first = buf_lo ? 5 : 0;
+  for (int side = 0; side < 2; side++) {
+    if (!(side == 0 ? buf_lo : buf_hi)) continue;
+    const int *moving = to_buf ? (side == 0 ? cxm : cxp) : (side == 0 ? cxp : cxm);
+    const int near = to_buf ? (side == 0 ? HALO : HALO + L->nx - 1) : (side == 0 ? HALO - 1 : HALO + L->nx);
+    for (int k = 0; k < 5; k++) { h.pop[h.n] = moving[k]; h.xp[h.n] = near; h.n++; }
+  }
+  if (h.n == 0) return HC_OK;
+  hipLaunchKernelGGL(halo_copy_kernel, dim3((unsigned)((L->plane + 255) / 256), (unsigned)h.n, 1), dim3(256), 0, hc::stream(), h);
+  HC_HIP(hipGetLastError());
+  return HC_OK;
+}
+int hcl_halo_pack_both(hc_lattice *L, double *dev_lo, double *dev_hi, int next) { return halo_copy_both(L, dev_lo, dev_hi, 1, next); }
+int hcl_halo_unpack_both(hc_lattice *L, const double *dev_lo, const double *dev_hi) { return halo_copy_both(L, (double *)dev_lo, (double *)dev_hi, 0, 0); }
 int hcl_halo_pack(hc_lattice *L, int side, int width, double *dev_buf) { return halo_copy(L, side, width, dev_buf, 1); }
 int hcl_halo_pack_next(hc_lattice *L, int side, int width, double *dev_buf) { return halo_copy(L, side, width, dev_buf, 1, 1); }
 int hcl_halo_unpack(hc_lattice *L, int side, int width, const double *dev_buf) { return halo_copy(L, side, width, (double *)dev_buf, 0); }

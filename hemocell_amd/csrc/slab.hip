@@ -26,6 +26,7 @@
 #include "comm.h"
 
 #include <chrono>
+#include <cstdlib>
 #include <map>
 #include <unordered_map>
 #include <unordered_set>
@@ -117,8 +118,11 @@ int halo_begin(Slab *S, int width, int next) {
   int lo, hi; hcm::neighbours(periodic_x(L), lo, hi);
   const int w = width - 1;
   int rc;
-  if (lo >= 0) { rc = next ? hcl_halo_pack_next(L, 0, width, S->hs[w][0]) : hcl_halo_pack(L, 0, width, S->hs[w][0]); if (rc != HC_OK) return rc; }
-  if (hi >= 0) { rc = next ? hcl_halo_pack_next(L, 1, width, S->hs[w][1]) : hcl_halo_pack(L, 1, width, S->hs[w][1]); if (rc != HC_OK) return rc; }
+  if (width == 1) { rc = hcl_halo_pack_both(L, lo >= 0 ? S->hs[0][0] : nullptr, hi >= 0 ? S->hs[0][1] : nullptr, next); if (rc != HC_OK) return rc; }   // one launch
+  else {
+    if (lo >= 0) { rc = next ? hcl_halo_pack_next(L, 0, width, S->hs[w][0]) : hcl_halo_pack(L, 0, width, S->hs[w][0]); if (rc != HC_OK) return rc; }
+    if (hi >= 0) { rc = next ? hcl_halo_pack_next(L, 1, width, S->hs[w][1]) : hcl_halo_pack(L, 1, width, S->hs[w][1]); if (rc != HC_OK) return rc; }
+  }
   const hipStream_t X = transfer_stream();
   if (X != hc::stream()) {
     // the unpack of the previous message precedes this pack in the packing stream, so the receive buffers are free again
@@ -140,8 +144,11 @@ int halo_finish(Slab *S) {
   const int width = S->pending_width, w = width - 1;
   int rc;
   if (transfer_stream() != hc::stream()) HC_HIP(hipStreamWaitEvent(hc::stream(), S->halo_arrived, 0));
-  if (lo >= 0) { rc = hcl_halo_unpack(L, 0, width, S->hr[w][0]); if (rc != HC_OK) return rc; }
-  if (hi >= 0) { rc = hcl_halo_unpack(L, 1, width, S->hr[w][1]); if (rc != HC_OK) return rc; }
+  if (width == 1) { rc = hcl_halo_unpack_both(L, lo >= 0 ? S->hr[0][0] : nullptr, hi >= 0 ? S->hr[0][1] : nullptr); if (rc != HC_OK) return rc; }   // one launch
+  else {
+    if (lo >= 0) { rc = hcl_halo_unpack(L, 0, width, S->hr[w][0]); if (rc != HC_OK) return rc; }
+    if (hi >= 0) { rc = hcl_halo_unpack(L, 1, width, S->hr[w][1]); if (rc != HC_OK) return rc; }
+  }
   S->pending_width = 0;
   S->halo_fresh = true;
   return HC_OK;
@@ -165,8 +172,7 @@ int velocity_exchange(Slab *S) {
   hc_lattice *L = S->L;
   int lo, hi; hcm::neighbours(periodic_x(L), lo, hi);
   int rc;
-  if (lo >= 0) { rc = hcl_face_velocity_pack(L, 0, S->us[0]); if (rc != HC_OK) return rc; }
-  if (hi >= 0) { rc = hcl_face_velocity_pack(L, 1, S->us[1]); if (rc != HC_OK) return rc; }
+  rc = hcl_face_velocity_pack_both(L, lo >= 0 ? S->us[0] : nullptr, hi >= 0 ? S->us[1] : nullptr); if (rc != HC_OK) return rc;   // one launch
   const hipStream_t X = transfer_stream();
   if (X != hc::stream()) {
     HC_HIP(hipEventRecord(S->u_packed, hc::stream()));   // also: every kernel that read the previous velocities precedes this point
@@ -413,18 +419,24 @@ int step(Slab *S, hc_cells *C, long it, int k_p, int force_limit, bool more) {
     TRY(hc::fork());
     hc::route(1);
     TRY(halo_make_fresh(S, 1));                    // the neighbours' faces (on their way since the previous step)
-    TRY(hcl_collide_stream_part(L, 4));            // the two planes next to each face, beside the interior ...
+    TRY(hcl_collide_stream_part(L, 6));            // the two planes next to each face (one launch), beside the interior ...
     TRY(halo_begin(S, 1, 1));                      // ... so that the crossing populations travel during the interior collide
+    TRY(hcl_zero_force_halos(L));                  // off the chain the message waits for
     hc::route(0);
     TRY(hcl_collide_stream_part(L, 3));            // main stream: planes 2 .. nx-3
     hcl_step_end(L);
+    // :327-332 for all cells, on the main stream right behind the interior collide -- BEFORE the neighbours' face velocities are
+    // here (the chain on the side stream below: a message that only arrives when the collide is over, an unpack, a kernel, a second
+    // message).  Only vertices within a node of a face read those velocities; they belong to cells within the envelope of the
+    // face, which are interpolated again once the velocities have arrived (sync_records) or take their owner's record
+    // (pure envelope copies).  Until then such vertices hold values formed from stale halo planes, which nothing reads.
+    TRY(hcp_interpolate(C));
     hc::route(1);
     TRY(halo_finish(S));                           // the neighbours' crossing populations -> halo planes of the new state
     TRY(velocity_exchange(S));                     // node velocities of my face planes (they read planes -1 .. 1) -> the neighbours' first halo plane
     TRY(hc::join());
     TRY(velocity_wait(S));
-    TRY(sync_records(S, plans, transfer_stream()));   // crossing cells interpolated first; their records leave on the transfer stream
-    TRY(hcp_interpolate(C));                       // :327-332, all cells, while the records travel
+    TRY(sync_records(S, plans, transfer_stream()));   // the cells near the faces again, with the neighbours' velocities; their records leave on the transfer stream
     TRY(sync_merge(S, plans, transfer_stream()));
     TRY(hcp_advance(C, 0));                        // :342
     TRY(hcp_mechanics(C, it, 0));                  // :345
@@ -434,8 +446,9 @@ int step(Slab *S, hc_cells *C, long it, int k_p, int force_limit, bool more) {
     TRY(hcl_collide_stream_part(L, 1));            // main stream: the planes that read no halo data
     hc::route(1);
     TRY(halo_make_fresh(S, 1));                    // faces of the neighbours (already here after a velocity update)
-    TRY(hcl_collide_stream_part(L, 2));            // the two face planes
+    TRY(hcl_collide_stream_part(L, 5));            // the two face planes (one launch)
     TRY(halo_begin(S, 1, 1));                      // my faces of the state being written leave for the NEXT step
+    TRY(hcl_zero_force_halos(L));                  // off the chain the message waits for
     hc::route(0);
     hcl_step_end(L);
     S->halo_fresh = false;

@@ -154,6 +154,9 @@ int hcl_slab_refresh_halos(hc_lattice *L, int width);
  * update can travel while part 3 runs).
  * hcl_step_end() flips the buffers. */
 int hcl_collide_stream_part(hc_lattice *L, int part);
+/* parts 5 and 6: as 2 and 4, but the halo planes of the IBM force buffer being retired are left for the caller to clear with
+ * hcl_zero_force_halos (before hcl_step_end) -- the slab schedule sends its face message first */
+int hcl_zero_force_halos(hc_lattice *L);
 int hcl_step_end(hc_lattice *L);
 /* populations in the reference's own layout: AoS [node][19], node = z + nz*(y + ny*x), values f_i - t_i
  * as Palabos stores them (post-stream state, i.e. what Cell::operator[] returns after collideAndStream) */
@@ -183,11 +186,16 @@ int hcl_halo_unpack(hc_lattice *L, int side, int width, const double *dev_buf);
 /* as hcl_halo_pack, but from the buffer the collide-stream in progress is writing (between
  * hcl_collide_stream_part(L, 4) and hcl_step_end): lets the message leave before the interior planes are done */
 int hcl_halo_pack_next(hc_lattice *L, int side, int width, double *dev_buf);
+/* the width-1 message of BOTH faces in one launch (what hc_iterate uses every step; a null buffer = no neighbour on that side);
+ * next != 0: from the buffer the collide in progress is writing */
+int hcl_halo_pack_both(hc_lattice *L, double *dev_lo, double *dev_hi, int next);
+int hcl_halo_unpack_both(hc_lattice *L, const double *dev_lo, const double *dev_hi);
 /* the message of a velocity update between slabs: node velocities u = j/rho + F/2 (Cell::computeVelocity for
  * ExternalForceDynamics, what core/hemoCellParticleField.cpp:833 blends) of this slab's face plane `side`, evaluated by
  * their owner on the post-stream state and packed as [3][ny*nz] doubles (device pointer) for the neighbour whose first halo
  * plane it is -- 3 planes instead of the 19 population planes of a width-2 halo.  hc_iterate exchanges them itself. */
 int hcl_face_velocity_pack(hc_lattice *L, int side, double *dev_buf);
+int hcl_face_velocity_pack_both(hc_lattice *L, double *dev_lo, double *dev_hi);   /* both face planes in one launch; a null buffer = no neighbour there */
 int hcl_download_face_velocity(hc_lattice *L, int side, double *host_u /*[3][ny*nz]*/);   /* the same plane on the host, for inspection */
 int hcl_dims(const hc_lattice *L, int dims[3]);
 /* counts[0] = bulk nodes of this slab, [1] = fluid nodes (GuoExternalForceBGKdynamics), [2] = nodes the collide kernel

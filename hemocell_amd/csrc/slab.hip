@@ -430,6 +430,8 @@ int step(Slab *S, hc_cells *C, long it, int k_p, int force_limit, bool more) {
     // message).  Only vertices within a node of a face read those velocities; they belong to cells within the envelope of the
     // face, which are interpolated again once the velocities have arrived (sync_records) or take their owner's record
     // (pure envelope copies).  Until then such vertices hold values formed from stale halo planes, which nothing reads.
+    // The planes next to the faces were collided on the side stream: its "packed" event (recorded behind them) comes first.
+    if (transfer_stream() != hc::stream()) HC_HIP(hipStreamWaitEvent(hc::stream(), S->halo_packed, 0));
     TRY(hcp_interpolate(C));
     hc::route(1);
     TRY(halo_finish(S));                           // the neighbours' crossing populations -> halo planes of the new state

@@ -66,13 +66,14 @@ struct hc_cells {
   unsigned int *d_keys[2] = {nullptr, nullptr}; int *d_vals[2] = {nullptr, nullptr}; void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0; long sort_cap = 0;
   // staged slot lists (envelope exchange, interpolate_cells, remove): pinned host block -> device block, stream ordered;
   // the event guards the pinned block against being rewritten while its copy is still in flight
-  int *d_iscratch[3] = {nullptr, nullptr, nullptr}, *h_iscratch[3] = {nullptr, nullptr, nullptr}; hipEvent_t iscratch_ev[3] = {nullptr, nullptr, nullptr};
+  // staged slot lists: 0, 1 envelope exchange; 2 reproducible spread; 3 + 2 * type + half: the two halves of a slab's velocity update
+  int *d_iscratch[19] = {nullptr}, *h_iscratch[19] = {nullptr}; hipEvent_t iscratch_ev[19] = {nullptr};
   // asynchronous cell extents (hcp_cell_extents_begin / _end): device block, pinned host block and event per type
   double *d_ext[8] = {nullptr}, *h_ext[8] = {nullptr}; long ext_cap[8] = {0}, ext_n[8] = {0}; hipEvent_t ext_done[8] = {nullptr}; bool ext_pending[8] = {false};
   // staging of hcp_add_vertex_force (called every iteration by the stretch drivers): pinned host block + device block
   // [n indices | 3n force components], grown on demand; the event guards the pinned block against reuse in flight
   char *h_vf = nullptr, *d_vf = nullptr; size_t vf_cap = 0; hipEvent_t vf_done = nullptr;
-  size_t iscratch_cap[3] = {0, 0, 0};
+  size_t iscratch_cap[19] = {0};
   // reproducible spread (hc_set_reproducible_spread): (node, entry) pairs of every (particle, stencil node), both sort buffers,
   // and the three force components of every entry
   unsigned int *det_keys[2] = {nullptr, nullptr}; int *det_vals[2] = {nullptr, nullptr}; double *det_val[3] = {nullptr, nullptr, nullptr};
@@ -210,6 +211,7 @@ VertArrays vert_arrays(hc_cells *C, int t);
 // stage a small host int array on the device in a persistent scratch slot (through a pinned block; stream ordered)
 int stage_ints(hc_cells *C, int which, int **d, const int *h, int n);
 void host_append_state(hc_cells *C, int type, long cell_id);
+int interpolate_cells_staged(hc_cells *C, int type, const int *slots, int n, int which);   // ibm.hip: hcp_interpolate_cells through staging slot `which`
 
 }  // namespace hcc
 using namespace hcc;

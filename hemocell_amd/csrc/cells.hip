@@ -371,7 +371,7 @@ int hcp_destroy(hc_cells *C) {
   if (C->ntag_ev) hipEventDestroy(C->ntag_ev);
   if (C->h_env_viol) hipHostFree(C->h_env_viol);
   if (C->d_bflag) hipFree(C->d_bflag);
-  for (int k = 0; k < 3; k++) { if (C->h_iscratch[k]) hipHostFree(C->h_iscratch[k]); if (C->iscratch_ev[k]) hipEventDestroy(C->iscratch_ev[k]); }
+  for (int k = 0; k < 19; k++) { if (C->h_iscratch[k]) hipHostFree(C->h_iscratch[k]); if (C->iscratch_ev[k]) hipEventDestroy(C->iscratch_ev[k]); }
   for (int k = 0; k < 2; k++) { if (C->det_keys[k]) hipFree(C->det_keys[k]); if (C->det_vals[k]) hipFree(C->det_vals[k]); }
   for (int k = 0; k < 3; k++) if (C->det_val[k]) hipFree(C->det_val[k]);
   if (C->det_tmp) hipFree(C->det_tmp);
@@ -383,7 +383,7 @@ int hcp_destroy(hc_cells *C) {
   if (C->h_vf) hipHostFree(C->h_vf);
   if (C->d_vf) hipFree(C->d_vf);
   if (C->vf_done) hipEventDestroy(C->vf_done);
-  for (int k = 0; k < 3; k++) if (C->d_iscratch[k]) hipFree(C->d_iscratch[k]);
+  for (int k = 0; k < 19; k++) if (C->d_iscratch[k]) hipFree(C->d_iscratch[k]);
   delete C;
   return HC_OK;
 }

@@ -761,14 +761,20 @@ int hcl_download_face_velocity(hc_lattice *L, int side, double *host_u) {
   return rc;
 }
 
-int hcp_interpolate_cells(hc_cells *C, int type, const int *slots, int n) {
-  HC_REQUIRE(C && type >= 0 && type < C->ntypes && n >= 0, "hcp_interpolate_cells: bad arguments");
+int hcp_interpolate_cells(hc_cells *C, int type, const int *slots, int n) { return hcc::interpolate_cells_staged(C, type, slots, n, 1); }
+
+}  // extern "C"
+
+// which: the staging slot the list travels through (a caller that issues several lists in one step gives each its own, so that
+// staging the next one does not wait for the copy of the previous one, which may sit behind a whole collide in the stream)
+int hcc::interpolate_cells_staged(hc_cells *C, int type, const int *slots, int n, int which) {
+  HC_REQUIRE(C && type >= 0 && type < C->ntypes && n >= 0 && which >= 0 && which < 19, "hcp_interpolate_cells: bad arguments");
   if (n == 0) return HC_OK;
   HC_REQUIRE(slots, "hcp_interpolate_cells: null pointer");
   int rc = sync_to_device(C); if (rc != HC_OK) return rc;
   for (int i = 0; i < n; i++) HC_REQUIRE(slots[i] >= 0 && slots[i] < C->ncells[type], "hcp_interpolate_cells: slot out of range");
   int *d_slots = nullptr;
-  rc = stage_ints(C, 1, &d_slots, slots, n); if (rc != HC_OK) return rc;
+  rc = stage_ints(C, which, &d_slots, slots, n); if (rc != HC_OK) return rc;
   hc::ProfScope prof(hc::PK_INTERP);
   const hc_lattice *L = C->L;
   const LatView v = make_view(L);
@@ -782,5 +788,3 @@ int hcp_interpolate_cells(hc_cells *C, int type, const int *slots, int n) {
   HC_HIP(hipGetLastError());
   return HC_OK;
 }
-
-}  // extern "C"

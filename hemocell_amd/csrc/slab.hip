@@ -425,20 +425,35 @@ int step(Slab *S, hc_cells *C, long it, int k_p, int force_limit, bool more) {
     hc::route(0);
     TRY(hcl_collide_stream_part(L, 3));            // main stream: planes 2 .. nx-3
     hcl_step_end(L);
-    // :327-332 for all cells, on the main stream right behind the interior collide -- BEFORE the neighbours' face velocities are
-    // here (the chain on the side stream below: a message that only arrives when the collide is over, an unpack, a kernel, a second
-    // message).  Only vertices within a node of a face read those velocities; they belong to cells within the envelope of the
-    // face, which are interpolated again once the velocities have arrived (sync_records) or take their owner's record
-    // (pure envelope copies).  Until then such vertices hold values formed from stale halo planes, which nothing reads.
+    // :327-332.  Only vertices within a node of a face read the neighbours' face velocities; they belong to cells within the
+    // envelope of the face -- the cells sync_records interpolates and sends -- or to pure envelope copies, which take their
+    // owner's record.  All OTHER cells depend on nothing that is still on its way, and there are two waits to fill: the chain on
+    // the side stream below (a message that only arrives when the collide is over, an unpack, a kernel, a second message), and
+    // the records of the crossing cells further down.  So the other cells are interpolated in two halves, one behind the
+    // interior collide, one behind the departure of the records.  (A vertex of such a cell never has a stencil node on a halo
+    // plane; a pure envelope copy may, its values are formed from stale planes and replaced by the merge.)
     // The planes next to the faces were collided on the side stream: its "packed" event (recorded behind them) comes first.
+    std::vector<std::vector<int>> rest((size_t)C->ntypes);
+    for (int t = 0; t < C->ntypes; t++) {
+      const Plan &P = plans[(size_t)t];
+      std::vector<char> near((size_t)P.n, 0);
+      for (int side = 0; side < 2; side++) for (int c : P.send[side]) near[(size_t)c] = 1;
+      for (long c = 0; c < P.n; c++) if (!near[(size_t)c] && P.ext[(size_t)(4 * c + 3)] != 1.0) rest[(size_t)t].push_back((int)c);
+    }
     if (transfer_stream() != hc::stream()) HC_HIP(hipStreamWaitEvent(hc::stream(), S->halo_packed, 0));
-    TRY(hcp_interpolate(C));
+    // first part: half of them, but at least what covers the ~0.1 ms of that chain (the kernel does 6-7 cells of 642 vertices per microsecond)
+    auto first_part = [&](int t) { const long n = (long)rest[(size_t)t].size(), v = 640L * 642 / C->types[t]->host.nv; return (int)std::min(n, std::max((n + 1) / 2, v)); };
+    for (int t = 0; t < C->ntypes; t++) { const int h = first_part(t); if (h) TRY(interpolate_cells_staged(C, t, rest[(size_t)t].data(), h, 3 + 2 * t)); }
     hc::route(1);
     TRY(halo_finish(S));                           // the neighbours' crossing populations -> halo planes of the new state
     TRY(velocity_exchange(S));                     // node velocities of my face planes (they read planes -1 .. 1) -> the neighbours' first halo plane
     TRY(hc::join());
     TRY(velocity_wait(S));
-    TRY(sync_records(S, plans, transfer_stream()));   // the cells near the faces again, with the neighbours' velocities; their records leave on the transfer stream
+    TRY(sync_records(S, plans, transfer_stream()));   // the cells near the faces, with the neighbours' velocities; their records leave on the transfer stream
+    for (int t = 0; t < C->ntypes; t++) {             // the second half of the others, while the records travel
+      const int h = first_part(t), n2 = (int)rest[(size_t)t].size() - h;
+      if (n2 > 0) TRY(interpolate_cells_staged(C, t, rest[(size_t)t].data() + h, n2, 4 + 2 * t));
+    }
     TRY(sync_merge(S, plans, transfer_stream()));
     TRY(hcp_advance(C, 0));                        // :342
     TRY(hcp_mechanics(C, it, 0));                  // :345

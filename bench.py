@@ -123,8 +123,31 @@ def cpu_baseline(args, budget_s):
         legs[name] = {"mlups": nx * ny * nz * steps / dt / 1e6, "steps": steps, "seconds": dt,
                       "vertex_updates_per_s": nverts * steps / dt}
         orc.orc_sim_destroy(S); L.destroy()
+    # one core (SURVEY 8d asks for it beside the all-cores figure): the one-pass form on a quarter-length piece of the same pipe, 5 iterations
+    nx1 = max(32, nx // 4)
+    mask1, _ = pipe_mask(nx1, ny, nz)
+    L = O.OracleLattice(orc, nx1, ny, nz, (1, 0, 0), 1.0 / P.tau)
+    L.set_threads(1); L.set_mask(mask1); L.init_equilibrium(); L.ptr.contents.fused = 1
+    S = orc.orc_sim_create(L.ptr, C.byref(P))
+    T = O.make_rbc(orc, P); T.contents.timescale = 20
+    orc.orc_sim_add_type(S, T); S.contents.particle_velocity_timescale = 5
+    if not args.fluid_only:
+        c1, a1 = pack_pipe_rbc(nx1, ny, nz, args.hematocrit)
+        for c, a in zip(c1, a1):
+            orc.orc_sim_add_cell(S, 0, O.dptr(np.ascontiguousarray(c)), O.dptr(np.array(a) * (3.14159265358979323846 / 180.0) * -1.0), 0.0)
+    L.set_force_uniform(F)
+    for d in range(3):
+        S.contents.body_force[d] = F[d]
+    orc.orc_sim_mechanics(S, 1); orc.orc_sim_iterate(S)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        orc.orc_sim_iterate(S)
+    dt1 = time.perf_counter() - t0
+    single = {"value": nx1 * ny * nz * 5 / dt1 / 1e6, "unit": "MLUPS", "cores": 1,
+              "sample": "pipe %dx%dx%d, %d vertices, iterations 1..5 in %.1f s, one-pass collide-stream" % (nx1, ny, nz, S.contents.np, dt1)}
+    orc.orc_sim_destroy(S); L.destroy()
     best = legs["fused"]
-    return {"value": best["mlups"], "unit": "MLUPS", "cores": cores, "kind": "port",
+    return {"value": best["mlups"], "single_core": single, "unit": "MLUPS", "cores": cores, "kind": "port",
             "mlups_per_core": best["mlups"] / cores,
             "sample_nodes_over_gpu_nodes": 1.0,
             "sample": "oracle (oracle/hemo_oracle.c, OpenMP collide-stream, IBM and mechanics) on the metric's own workload: pipe "

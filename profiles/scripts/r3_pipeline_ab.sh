@@ -1,4 +1,5 @@
 #!/bin/bash
+# record of a dropped experiment: the HEMOCELL_PIPELINE_CHUNKS switch this script drives was removed again (profiles/r03_f_pipelined_velocity_update_ab.txt)
 mkdir -p gpurun_out/r3k
 for r in 1 2 3; do
   for mode in 1 4 8; do
